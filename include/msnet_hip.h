@@ -1,0 +1,135 @@
+/*
+ * msnet_hip.h -- C ABI of libmsnet_hip.so: the MI355X (gfx950) implementation of the MS-Nets
+ * cost-volume forward pass (matching-space volume build -> 3D conv aggregator -> soft-argmin).
+ *
+ * The reference (ccj5351/MS-Nets) has no C ABI for this path: its boundary is two Python surfaces,
+ * (1) the Boost.Python extension modules libmatchers / libfeatextract and (2) the two aggregator
+ * nn.Modules.  Every entry point below names the reference interface it replaces (paths relative to
+ * the reference root).  The Python mirror of those surfaces lives in ms-nets_amd/ and calls this
+ * library through ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing synchronises;
+ *   - no entry point allocates: callers own all buffers, sizes are given by the *_bytes / *_floats helpers;
+ *   - return value: 0 on success, non-zero on error; msnet_last_error() returns a static thread-local
+ *     message for the last failure on the calling thread;
+ *   - activations inside the aggregator are channels-last fp32 ("NDHWC": [N][D][H][W][C]);
+ *     the reference's NCDHW tensors are converted at the module boundary by msnet_ncdhw_to_ndhwc.
+ */
+#ifndef MSNET_HIP_H
+#define MSNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* msnet_stream_t;
+
+/* ---- library -------------------------------------------------------------------------------- */
+int         msnet_version(void);                 /* ABI version, currently 1 */
+const char* msnet_last_error(void);
+/* Per-kernel timing with HIP events on the launch stream (bench.py roofline).  enable(1) makes
+ * every launch record start/stop events; collect() synchronises those events and writes one line
+ * "name calls total_ms flops bytes\n" per kernel into buf (returns bytes written, <0 on error) and
+ * clears the log. */
+int         msnet_prof_enable(int on);
+long        msnet_prof_collect(char* buf_host, size_t buf_bytes);
+
+/* ---- matchers: replaces src/cpp/matchers/matchers.cpp:565-580 (libmatchers) ----------------- */
+/* census(left,right,ndisp,wsize) matchers.cpp:232-353.  l,r: u8[H][W]; out: f32[H][W][ndisp];
+ * workspace: msnet_census_workspace_bytes(H,W,wsize) bytes (the two census bit images). */
+int    msnet_census(const uint8_t* l, const uint8_t* r, float* out, void* workspace, int H, int W, int ndisp,
+                    int wsize, msnet_stream_t stream);
+size_t msnet_census_workspace_bytes(int H, int W, int wsize);
+/* nccNister(left,right,ndisp,wsize) matchers.cpp:47-228.  out: f32[ndisp][H][W]. */
+int msnet_ncc(const uint8_t* l, const uint8_t* r, float* out, int H, int W, int ndisp, int wsize,
+              msnet_stream_t stream);
+/* zsad(left,right,ndisp,wsize) matchers.cpp:442-512.  out: f32[ndisp][H][W]. */
+int msnet_zsad(const uint8_t* l, const uint8_t* r, float* out, int H, int W, int ndisp, int wsize,
+               msnet_stream_t stream);
+/* sobel(img) matchers.cpp:515-554.  img: u8[H][W]; out: f32[H][W]. */
+int msnet_sobel(const uint8_t* img, float* out, int H, int W, msnet_stream_t stream);
+/* sadsob(sobl,sobr,ndisp,wsize) matchers.cpp:356-438.  sl,sr: f32[H][W]; out: f32[ndisp][H][W];
+ * workspace: msnet_sadsob_workspace_bytes(H,W,ndisp) bytes. */
+int    msnet_sadsob(const float* sl, const float* sr, float* out, void* workspace, int H, int W,
+                    int ndisp, int wsize, msnet_stream_t stream);
+size_t msnet_sadsob_workspace_bytes(int H, int W, int ndisp);
+
+/* ---- featextract: replaces src/cpp/featextract/featextract.cpp:529-553 (libfeatextract) ----- */
+/* swap_axes(cost) featextract.cpp:49-76.  in: f32[D][H][W] -> out: f32[H][W][D]. */
+int msnet_swap_axes(const float* in, float* out, int D, int H, int W, msnet_stream_t stream);
+/* extract_likelihood(vol,sigma) = extract_aml_testing, featextract.cpp:415-462.  vol,out: f32[P][D]. */
+int msnet_extract_likelihood(const float* vol, float* out, long P, int D, float sigma,
+                             msnet_stream_t stream);
+
+/* ---- fused volume build: replaces get_costs + extract_features_left,
+ *      src/dataloader/cbmv_generator.py:27-79 and :258-308 ------------------------------------- */
+typedef struct msnet_volume_params {
+    int   censw, nccw, sadw, sobelw;       /* 11, 3, 5, 5  (cbmv_generator.py:434-462) */
+    float cens_sigma, ncc_sigma, sad_sigma; /* 128, 0.02, 20000 (sobel channel uses sad_sigma, :298,303) */
+    int   border_h, border_w;              /* 10, 10 (cbmv_generator.py:819-823) */
+} msnet_volume_params;
+void   msnet_volume_default_params(msnet_volume_params* p_host);
+/* l,r: u8[Hb][Wb] bordered images (Hb = H'+2*border_h, Wb = W'+2*border_w); ndisp = D';
+ * out: f32[8][D'][H'][W'] -- the reference's feature layout (cbmv_generator.py:307-308). */
+int    msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int ndisp,
+                          const msnet_volume_params* p_host, void* workspace, float* out,
+                          msnet_stream_t stream);
+size_t msnet_build_volume_workspace_bytes(int Hb, int Wb, int ndisp);
+
+/* ---- aggregator building blocks: replace the torch.nn calls inside
+ *      src/models/gcnet_3dcnn.py:20-27,97-141 and src/models/psmnet_3dcnn.py:22-25,69-89,126-179 */
+int msnet_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, int D, int H, int W,
+                         msnet_stream_t stream);
+int msnet_ndhwc_to_ncdhw(const float* src, float* dst, int N, int C, int D, int H, int W,
+                         msnet_stream_t stream);
+
+/* Weight repacking into the MFMA operand order used by the conv kernels.
+ * conv:   w f32[Co][Ci][3][3][3] (nn.Conv3d.weight)           -> packed, msnet_packed_weight_floats(Ci,Co) floats
+ * deconv: w f32[Ci][Co][3][3][3] (nn.ConvTranspose3d.weight)  -> same packed size */
+size_t msnet_packed_weight_floats(int Ci, int Co);
+int    msnet_pack_conv_weight(const float* w, float* packed, int Ci, int Co, msnet_stream_t stream);
+int    msnet_pack_deconv_weight(const float* w, float* packed, int Ci, int Co, msnet_stream_t stream);
+
+/* convbn_3d (+ReLU, + residual): y = act( conv3d_k3_p1_stride(x) * scale[co] + shift[co] (+ residual) ).
+ * gcnet_3dcnn.py:20-22, psmnet_3dcnn.py:22-25.  x: NDHWC [N][D][H][W][Ci]; y/residual: [N][OD][OH][OW][Co],
+ * OD = (D-1)/stride+1 etc.  scale/shift: the eval-mode BatchNorm3d affine (NULL = identity / zero).
+ * Ci in {8} or a multiple of 16; Co a multiple of 32; stride 1 or 2. */
+int msnet_conv3d_k3(const float* x, const float* wpk, const float* scale, const float* shift,
+                    const float* residual, float* y, int N, int D, int H, int W, int Ci, int Co,
+                    int stride, int relu, msnet_stream_t stream);
+/* deconvbn_3d: ConvTranspose3d(k3,s2,p1,op1) + BN (+ residual) (+ReLU).  gcnet_3dcnn.py:24-27,
+ * psmnet_3dcnn.py:41-44,63-67.  x: [N][D][H][W][Ci] -> y: [N][2D][2H][2W][Co]. */
+int msnet_deconv3d_k3s2(const float* x, const float* wpk, const float* scale, const float* shift,
+                        const float* residual, float* y, int N, int D, int H, int W, int Ci, int Co,
+                        int relu, msnet_stream_t stream);
+/* Conv3d(Ci->1, k3, p1, bias=False) head (psmnet_3dcnn.py:112-122 classif*.2), optional "+ add"
+ * (cost2 = classif2(out2) + cost1, :146-147).  x: NDHWC; w: f32[1][Ci][3][3][3]; y/add: f32[N][D][H][W]. */
+int msnet_conv3d_k3_cout1(const float* x, const float* w, const float* add, float* y, int N, int D,
+                          int H, int W, int Ci, msnet_stream_t stream);
+
+/* ---- tails ---------------------------------------------------------------------------------- */
+/* softmax over D + sum_d d*p_d.  gcnet_3dcnn.py:126-141.  logits f32[N][D][H][W] -> disp f32[N][H][W]. */
+int msnet_softargmin(const float* logits, float* disp, int N, int D, int H, int W, msnet_stream_t stream);
+/* deconv5 (ConvTranspose3d Ci->1, k3, s2, p1, op1, bias) fused with the soft-argmin: the [N][2D][2H][2W]
+ * logit volume is never written.  gcnet_3dcnn.py:124-141.  x: NDHWC [N][D][H][W][Ci];
+ * w: f32[Ci][1][3][3][3]; bias_host: the scalar bias; disp: f32[N][2H][2W]. */
+int msnet_deconv5_softargmin(const float* x, const float* w, float bias_host, float* disp, int N, int D,
+                             int H, int W, int Ci, msnet_stream_t stream);
+/* Un-fused deconv5 (stride 2 or the is_quarter_input_size stride-4/op-3 variant, gcnet_3dcnn.py:88-92).
+ * logits: f32[N][s*D][s*H][s*W]. */
+int msnet_deconv3d_cout1(const float* x, const float* w, float bias_host, float* logits, int N, int D,
+                         int H, int W, int Ci, int stride, msnet_stream_t stream);
+/* F.interpolate(trilinear, align_corners=True) to [D][H][W] fused with softmax + regression.
+ * psmnet_3dcnn.py:167-174.  cost f32[N][d][h][w] -> disp f32[N][H][W]. */
+int msnet_trilinear_softargmin(const float* cost, float* disp, int N, int d, int h, int w, int D, int H,
+                               int W, msnet_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSNET_HIP_H */

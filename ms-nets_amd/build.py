@@ -1,0 +1,70 @@
+"""Builds libmsnet_hip.so (gfx950) in-tree with hipcc.  No torch, no cmake: the library is a plain
+C-ABI shared object (include/msnet_hip.h) that is loaded with ctypes.
+
+    python -m ms-nets_amd.build            # or: from __graft_entry__ import build; build()
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmsnet_hip.so")
+ARCH = "gfx950"
+
+# (source, extra flags).  volume.hip reproduces float32 operation order => no FMA contraction there.
+SOURCES = [
+    ("api.cpp", []),
+    ("pack.hip", []),
+    ("conv3d.hip", []),
+    ("tail.hip", []),
+    ("volume.hip", ["-ffp-contract=off"]),
+]
+COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
+          "-fno-gpu-rdc"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    hipcc = _hipcc()
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "msnet_hip.h"),
+               os.path.abspath(__file__)]
+    objs = []
+    procs = []
+    for src, extra in SOURCES:
+        sp = os.path.join(CSRC, src)
+        op = os.path.join(objdir, src + ".o")
+        objs.append(op)
+        if force or _stale(op, [sp] + headers):
+            cmd = [hipcc, "-x", "hip"] + COMMON + extra + ["-c", sp, "-o", op]
+            if verbose:
+                print("[build]", " ".join(cmd), flush=True)
+            procs.append((src, subprocess.Popen(cmd)))
+    failed = [s for s, p in procs if p.wait() != 0]
+    if failed:
+        raise RuntimeError("hipcc failed for: " + ", ".join(failed))
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+        if verbose:
+            print("[build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

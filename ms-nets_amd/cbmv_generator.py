@@ -1,0 +1,102 @@
+"""Cost-volume assembly on the GPU, mirroring the two functions of the reference's
+src/dataloader/cbmv_generator.py that sit on the hot path:
+
+  get_costs(iml, imr, maxdisp, censw, nccw, sadw, sobelw, board_h, board_w_left, board_w_right)   :27-79
+  extract_features_left(census, ncc, sobel, sad, cens_sigma, ncc_sigma, sad_sigma, sobel_sigma)  :258-308
+
+plus the fused entry point the reference does not have: build_ms_volume(imgl_board, imgr_board, ndisp),
+which goes from the two bordered uint8 images to the [8, D', H', W'] float32 volume in one C-ABI call
+without leaving the device.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib, libfeatextract as fte, libmatchers as mtc
+from ._lib import check, ptr, stream_ptr
+
+
+def get_default_args_dict():
+    """The hot-path constants of cbmv_generator.py:434-462."""
+    return dict(censw=11, nccw=3, sadw=5, sobelw=5, cens_sigma=128.0, ncc_sigma=0.02, sad_sigma=20000.0,
+                sobel_sigma=20000.0, cbmv_F=8, ds_scale=2, board_h=10)
+
+
+def _crop(c, board_h, board_w_left, board_w_right):
+    w_end = -board_w_right if board_w_right > 0 else None
+    h_end = -board_h if board_h > 0 else None
+    c = c[board_h:h_end, board_w_left:w_end, :]
+    return c.copy(order="C") if isinstance(c, np.ndarray) else c.contiguous()
+
+
+def get_costs(iml, imr, maxdisp=192, censw=11, nccw=3, sadw=5, sobelw=5, board_h=10, board_w_left=10, board_w_right=0):
+    """Four raw matching costs, each [H', W', ndisp] float32, returned as (census, ncc, sobel, sad)."""
+    costcensus = mtc.census(iml, imr, maxdisp, censw)
+    costncc = fte.swap_axes(mtc.nccNister(iml, imr, maxdisp, nccw))
+    costsad = fte.swap_axes(mtc.zsad(iml, imr, maxdisp, sadw))
+    costsob = fte.swap_axes(mtc.sadsob(mtc.sobel(iml), mtc.sobel(imr), maxdisp, sobelw))
+    return tuple(_crop(c, board_h, board_w_left, board_w_right) for c in (costcensus, costncc, costsob, costsad))
+
+
+def extract_features_left(census, ncc, sobel, sad, cens_sigma=128.0, ncc_sigma=0.02, sad_sigma=20000.0,
+                          sobel_sigma=20000.0, disp_image=None):
+    """-> [8, ndisp, H', W'] float32.  The 4 normalisations are elementwise plumbing (torch / NumPy, float32,
+    the reference's own expressions); the 4 likelihood channels run in the HIP library.  As in the reference
+    the Sobel channel's likelihood uses sad_sigma and sobel_sigma is ignored (:298,303)."""
+    was_numpy = isinstance(census, np.ndarray)
+    if was_numpy:
+        census, ncc, sobel, sad = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (census, ncc, sobel, sad))
+    h, w, nd = census.shape
+    flat = lambda a: a.reshape(h * w, nd)   # noqa: E731
+    feats = torch.empty((8, h, w, nd), device=census.device, dtype=torch.float32)
+    feats[0] = torch.clamp(census, 0., 120.) / 120.
+    feats[1] = (1 + torch.clamp(ncc, -1., 1.)) / 2
+    feats[2] = torch.clamp(sobel, 0., 2. ** 13) / float(2 ** 13)
+    feats[3] = torch.clamp(sad, 0., 2. ** 13) / float(2 ** 13)
+    feats[4] = fte.extract_likelihood(flat(census), cens_sigma).reshape(h, w, nd)
+    feats[5] = fte.extract_likelihood(flat(ncc), ncc_sigma).reshape(h, w, nd)
+    feats[6] = fte.extract_likelihood(flat(sobel), sad_sigma).reshape(h, w, nd)
+    feats[7] = fte.extract_likelihood(flat(sad), sad_sigma).reshape(h, w, nd)
+    out = feats.permute(0, 3, 1, 2).contiguous()
+    return out.cpu().numpy() if was_numpy else out
+
+
+class VolumeBuilder:
+    """Fused build: owns the workspace for one (Hb, Wb, ndisp) shape so repeated calls allocate nothing."""
+
+    def __init__(self, Hb, Wb, ndisp, device="cuda", params=None):
+        lib = _lib.load()
+        self.Hb, self.Wb, self.nd = int(Hb), int(Wb), int(ndisp)
+        self.params = _lib.VolumeParams()
+        lib.msnet_volume_default_params(ctypes.byref(self.params))
+        for k, v in (params or {}).items():
+            setattr(self.params, k, v)
+        self.Hc = self.Hb - 2 * self.params.border_h
+        self.Wc = self.Wb - 2 * self.params.border_w
+        nbytes = lib.msnet_build_volume_workspace_bytes(self.Hb, self.Wb, self.nd)
+        self.workspace = torch.empty(max(1, nbytes), device=device, dtype=torch.uint8)
+
+    def __call__(self, imgl, imgr, out=None):
+        imgl = _lib.require_gpu_f32(imgl, "imgl", torch.uint8)
+        imgr = _lib.require_gpu_f32(imgr, "imgr", torch.uint8)
+        if tuple(imgl.shape) != (self.Hb, self.Wb) or imgl.shape != imgr.shape:
+            raise ValueError("expected two [%d,%d] uint8 images" % (self.Hb, self.Wb))
+        if out is None:
+            out = torch.empty((8, self.nd, self.Hc, self.Wc), device=imgl.device, dtype=torch.float32)
+        check(_lib.load().msnet_build_volume(ptr(imgl), ptr(imgr), self.Hb, self.Wb, self.nd, ctypes.byref(self.params),
+                                             ptr(self.workspace), ptr(out), stream_ptr()), "msnet_build_volume")
+        return out
+
+
+def build_ms_volume(imgl_board, imgr_board, ndisp, params=None):
+    """Two bordered uint8 images [Hb, Wb] (NumPy or GPU tensors) -> [8, ndisp, Hb-2*border, Wb-2*border]."""
+    was_numpy = isinstance(imgl_board, np.ndarray)
+    if was_numpy:
+        if not torch.cuda.is_available():
+            raise RuntimeError("build_ms_volume (HIP): no MI355X device visible and there is no CPU fallback")
+        imgl_board = torch.from_numpy(np.ascontiguousarray(imgl_board)).cuda()
+        imgr_board = torch.from_numpy(np.ascontiguousarray(imgr_board)).cuda()
+    vb = VolumeBuilder(imgl_board.shape[0], imgl_board.shape[1], ndisp, imgl_board.device, params)
+    out = vb(imgl_board, imgr_board)
+    return out.cpu().numpy() if was_numpy else out

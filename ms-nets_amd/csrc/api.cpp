@@ -1,0 +1,97 @@
+// Library-level plumbing of libmsnet_hip.so: error strings and the per-launch HIP-event profiler.
+#include <stdarg.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace msnet {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int fail(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return 1;
+}
+
+struct Rec {
+    const char* name;
+    hipEvent_t a, b;
+    double flops, bytes;
+};
+static std::mutex g_mu;
+static std::vector<Rec*> g_recs;
+static volatile int g_prof = 0;
+
+LaunchScope::LaunchScope(const char* n, hipStream_t s, double flops, double bytes) : name(n), stream(s), rec(nullptr) {
+    if (!g_prof) return;
+    Rec* r = new Rec{n, nullptr, nullptr, flops, bytes};
+    if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return; }
+    hipEventRecord(r->a, s);
+    rec = r;
+}
+
+LaunchScope::~LaunchScope() {
+    if (!rec) return;
+    Rec* r = static_cast<Rec*>(rec);
+    hipEventRecord(r->b, stream);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_recs.push_back(r);
+}
+
+}  // namespace msnet
+
+using namespace msnet;
+
+extern "C" int msnet_version(void) { return 1; }
+extern "C" const char* msnet_last_error(void) { return g_err; }
+
+extern "C" int msnet_prof_enable(int on) {
+    g_prof = on ? 1 : 0;
+    return 0;
+}
+
+extern "C" long msnet_prof_collect(char* buf, size_t n) {
+    std::vector<Rec*> recs;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        recs.swap(g_recs);
+    }
+    struct Agg { long calls = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Agg> agg;
+    for (Rec* r : recs) {
+        float ms = 0.f;
+        if (hipEventSynchronize(r->b) == hipSuccess && hipEventElapsedTime(&ms, r->a, r->b) == hipSuccess) {
+            Agg& g = agg[r->name];
+            g.calls++; g.ms += ms; g.flops += r->flops; g.bytes += r->bytes;
+        }
+        hipEventDestroy(r->a);
+        hipEventDestroy(r->b);
+        delete r;
+    }
+    size_t off = 0;
+    for (auto& kv : agg) {
+        char line[256];
+        int k = snprintf(line, sizeof(line), "%s %ld %.6f %.6e %.6e\n", kv.first.c_str(), kv.second.calls, kv.second.ms,
+                         kv.second.flops, kv.second.bytes);
+        if (k < 0) continue;
+        if (!buf || off + (size_t)k + 1 > n) { fail("msnet_prof_collect: buffer too small"); return -1; }
+        memcpy(buf + off, line, (size_t)k);
+        off += (size_t)k;
+    }
+    if (buf && off < n) buf[off] = 0;
+    return (long)off;
+}

@@ -1,0 +1,428 @@
+// 3x3x3 convolutions of the cost-volume aggregators as implicit GEMMs on the fp32-input MFMA
+// (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate -- the parity-safe matrix path on gfx950).
+//
+// Replaces the nn.Conv3d / nn.ConvTranspose3d + nn.BatchNorm3d (+ReLU, +skip) stacks of
+//   /root/reference/src/models/gcnet_3dcnn.py:20-27,97-122  and  psmnet_3dcnn.py:22-25,41-89,96-122.
+//
+// Data layout in HBM: activations are channels-last fp32, [N][D][H][W][C]; one voxel's C channels are
+// one contiguous 128/256/512-byte run, so every global access below is a full-line access.
+//
+// Implicit GEMM:  out[pos][co] = sum_{tap, ci} in[pos (+) tap][ci] * w[co][ci][tap]
+//   M = 32 output voxels (an "M-block": BH x BW voxels of one depth slice), N = 32 output channels,
+//   K = 27 taps x Ci, walked 8 input channels at a time.
+// A workgroup (4 waves, one per SIMD, 256 threads) stages the input tile + halo for one chunk of CC
+// input channels in LDS once and re-reads it for all 27 taps and all output channels; the B operand
+// (weights, pre-packed on the device into MFMA lane order by pack.hip) streams from L2 one tap ahead.
+//
+// MFMA operand maps (cdna_hip_programming.md section 3): for v_mfma_f32_32x32x2_f32 lane l holds
+// A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; D[i][j] sits in lane (j | 32*((i>>2)&1)),
+// register (i&3) + 4*(i>>3).  The K order inside an 8-channel group is permuted so that one 16-byte
+// ds_read_b128 / global_load_dwordx4 per lane feeds four consecutive MFMAs: lane half h reads
+// channels 8q+4h .. 8q+4h+3 and MFMA t consumes channel 8q+4h+t from each half (the weights are
+// packed with the same permutation, so the sum over K is unchanged).
+#include "common.h"
+
+namespace msnet {
+
+struct ConvArgs {
+    const float* x; const f32x4* wpk; const float* scale; const float* shift; const float* res; float* y;
+    int N, D, H, W;        // input spatial dims
+    int OD, OH, OW;        // output spatial dims
+    int Ci, Co;
+    int relu;
+    int ntd, nth, ntw;     // tiles per dim (conv: over output dims; deconv: over input dims)
+    int ngroups;           // Co / (32 * WN * NB)
+    int nbtot;             // Co / 32
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Stage NPOS voxels x CC channels (global NDHWC, channel offset c0 of Ci) into LDS [pos][CC+4].
+// Voxels outside the input are the convolution's zero padding.
+template <int CC, int ID, int IH, int IW>
+__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ x, int n, int D, int H,
+                                           int W, int Ci, int c0, int id0, int ih0, int iw0, int tid) {
+    constexpr int PS = CC + 4;
+    constexpr int V = CC / 4;                 // float4 per voxel
+    constexpr int NSLOT = ID * IH * IW * V;
+    constexpr int U = 8;                      // loads in flight per thread
+    for (int base = 0; base < NSLOT; base += 256 * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int slot = base + u * 256 + tid;
+            const int pos = slot / V, c4 = slot % V;
+            const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
+            const int gd = id0 + id, gh = ih0 + ih, gw = iw0 + iw;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (slot < NSLOT && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H &&
+                (unsigned)gw < (unsigned)W) {
+                const size_t vox = (((size_t)n * D + gd) * H + gh) * W + gw;
+                v[u] = *reinterpret_cast<const f32x4*>(x + vox * Ci + c0 + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int slot = base + u * 256 + tid;
+            if (slot < NSLOT) {
+                const int pos = slot / V, c4 = slot % V;
+                *reinterpret_cast<f32x4*>(lds + pos * PS + c4 * 4) = v[u];
+            }
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void load_b(f32x4 (&b)[NB], const f32x4* __restrict__ p) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b[j] = p[j * 64];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward conv, kernel 3, pad 1, stride STRIDE.
+//   tile: TD x TH x TW output voxels = WM*MB M-blocks of (32/BW) x BW voxels; WN*NB N-blocks.
+// ---------------------------------------------------------------------------------------------
+template <int CC, int STRIDE, int TD, int TH, int TW, int BW, int WM, int WN, int MB, int NB>
+__global__ __launch_bounds__(256, 1) void conv3d_k3_mfma(ConvArgs a) {
+    constexpr int BH = 32 / BW;
+    constexpr int ID = (TD - 1) * STRIDE + 3, IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
+    constexpr int PS = CC + 4;
+    constexpr int NQ = CC / 8;
+    constexpr int MW = TW / BW, MH = TH / BH;
+    static_assert(TD * MH * MW == WM * MB, "M-block count mismatch");
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float lds[ID * IH * IW * PS];
+
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int g = bid % a.ngroups; bid /= a.ngroups;
+    const int tw = bid % a.ntw; bid /= a.ntw;
+    const int th = bid % a.nth; bid /= a.nth;
+    const int td = bid % a.ntd;
+    const int n = bid / a.ntd;
+    const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int r = lane & 31, hh = lane >> 5;
+
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    int abase[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int mb = wm * MB + i;
+        const int bw = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
+        const int lh = bh * BH + r / BW, lw = bw * BW + r % BW;
+        abase[i] = ((bd * STRIDE * IH + lh * STRIDE) * IW + lw * STRIDE) * PS + 4 * hh;
+    }
+    const int nb0 = (g * WN + wn) * NB;
+    const int nci8 = a.Ci >> 3;
+    const int nchunks = a.Ci / CC;
+
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();
+        stage_tile<CC, ID, IH, IW>(lds, a.x, n, a.D, a.H, a.W, a.Ci, chunk * CC, od0 * STRIDE - 1,
+                                   oh0 * STRIDE - 1, ow0 * STRIDE - 1, tid);
+        __syncthreads();
+
+        // weights for (tap, q): wpk[((tap*nci8 + chunk*NQ + q) * nbtot + nb) * 64 + lane]
+        const f32x4* wbase = a.wpk + ((size_t)(chunk * NQ) * a.nbtot + nb0) * 64 + lane;
+        const size_t wtap = (size_t)nci8 * a.nbtot * 64;
+        const size_t wq = (size_t)a.nbtot * 64;
+
+        f32x4 bq[2][NQ][NB];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) load_b<NB>(bq[0][q], wbase + q * wq);
+
+#pragma unroll
+        for (int tap = 0; tap < 27; ++tap) {
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int toff = ((kd * IH + kh) * IW + kw) * PS;
+            if (tap + 1 < 27) {
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) load_b<NB>(bq[(tap + 1) & 1][q], wbase + (tap + 1) * wtap + q * wq);
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                f32x4 av[MB];
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+                    av[i] = *reinterpret_cast<const f32x4*>(lds + abase[i] + toff + q * 8);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < MB; ++i)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j)
+                            acc[i][j] = mfma32(av[i][t], bq[tap & 1][q][j][t], acc[i][j]);
+            }
+        }
+    }
+
+    // Epilogue: BN affine (+ skip) (+ ReLU); for one accumulator register the 32 lanes of a half hold the
+    // 32 channels of one voxel => each store instruction writes two full 128-byte lines.
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int mb = wm * MB + i;
+        const int bw = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
+        const int od = od0 + bd;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int co = (nb0 + j) * 32 + r;
+            const float sc = a.scale ? a.scale[co] : 1.f;
+            const float sh = a.shift ? a.shift[co] : 0.f;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                const int oh = oh0 + bh * BH + row / BW, ow = ow0 + bw * BW + row % BW;
+                if (od < a.OD && oh < a.OH && ow < a.OW) {
+                    const size_t idx = ((((size_t)n * a.OD + od) * a.OH + oh) * a.OW + ow) * a.Co + co;
+                    float v = acc[i][j][e] * sc + sh;
+                    if (a.res) v += a.res[idx];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.y[idx] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transposed conv, kernel 3, stride 2, pad 1, output_padding 1 (out = 2 x in), as 8 output-parity
+// classes sharing one LDS tile.  o = 2i - 1 + k per dim: an even output 2j takes only (k=1, i=j); an odd
+// output 2j+1 takes (k=2, i=j) and (k=0, i=j+1).  Class (pd,ph,pw) therefore has 2^(pd+ph+pw) taps; the
+// 27 (class, tap) pairs do exactly the 27*Ci*Co MACs per input voxel of the dense definition.
+// The whole Ci is resident in LDS (no chunk loop) so classes can be finished one after another with a
+// single live accumulator set.  Weights use the same packed order, indexed by the ConvTranspose3d tap.
+// ---------------------------------------------------------------------------------------------
+template <int CI, int TD, int TH, int TW, int BW, int WM, int WN, int MB, int NB>
+__global__ __launch_bounds__(256, 1) void deconv3d_k3s2_mfma(ConvArgs a) {
+    constexpr int BH = 32 / BW;
+    constexpr int ID = TD + 1, IH = TH + 1, IW = TW + 1;
+    constexpr int PS = CI + 4;
+    constexpr int NQ = CI / 8;
+    constexpr int MW = TW / BW, MH = TH / BH;
+    static_assert(TD * MH * MW == WM * MB, "M-block count mismatch");
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float lds[ID * IH * IW * PS];
+
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int g = bid % a.ngroups; bid /= a.ngroups;
+    const int tw = bid % a.ntw; bid /= a.ntw;
+    const int th = bid % a.nth; bid /= a.nth;
+    const int td = bid % a.ntd;
+    const int n = bid / a.ntd;
+    const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave % WM, wn = wave / WM;
+    const int r = lane & 31, hh = lane >> 5;
+
+    stage_tile<CI, ID, IH, IW>(lds, a.x, n, a.D, a.H, a.W, a.Ci, 0, d0, h0, w0, tid);
+    __syncthreads();
+
+    int abase[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int mb = wm * MB + i;
+        const int bw = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
+        const int lh = bh * BH + r / BW, lw = bw * BW + r % BW;
+        abase[i] = ((bd * IH + lh) * IW + lw) * PS + 4 * hh;
+    }
+    const int nb0 = (g * WN + wn) * NB;
+    const size_t wtap = (size_t)NQ * a.nbtot * 64;
+    const size_t wq = (size_t)a.nbtot * 64;
+    const f32x4* wbase = a.wpk + (size_t)nb0 * 64 + lane;
+
+#pragma unroll
+    for (int cls = 0; cls < 8; ++cls) {
+        const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
+        f32x16 acc[MB][NB];
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#pragma unroll
+        for (int dd = 0; dd <= pd; ++dd)
+#pragma unroll
+            for (int dh = 0; dh <= ph; ++dh)
+#pragma unroll
+                for (int dw = 0; dw <= pw; ++dw) {
+                    const int kd = pd ? (dd ? 0 : 2) : 1;
+                    const int kh = ph ? (dh ? 0 : 2) : 1;
+                    const int kw = pw ? (dw ? 0 : 2) : 1;
+                    const int tap = (kd * 3 + kh) * 3 + kw;
+                    const int toff = ((dd * IH + dh) * IW + dw) * PS;
+                    const f32x4* wp = wbase + tap * wtap;
+#pragma unroll 4
+                    for (int q = 0; q < NQ; ++q) {
+                        f32x4 bv[NB];
+                        load_b<NB>(bv, wp + q * wq);
+                        f32x4 av[MB];
+#pragma unroll
+                        for (int i = 0; i < MB; ++i)
+                            av[i] = *reinterpret_cast<const f32x4*>(lds + abase[i] + toff + q * 8);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                                for (int j = 0; j < NB; ++j)
+                                    acc[i][j] = mfma32(av[i][t], bv[j][t], acc[i][j]);
+                    }
+                }
+
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int mb = wm * MB + i;
+            const int bw = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
+            const int id = d0 + bd;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int co = (nb0 + j) * 32 + r;
+                const float sc = a.scale ? a.scale[co] : 1.f;
+                const float sh = a.shift ? a.shift[co] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    const int ih = h0 + bh * BH + row / BW, iw = w0 + bw * BW + row % BW;
+                    if (id < a.D && ih < a.H && iw < a.W) {
+                        const int od = 2 * id + pd, oh = 2 * ih + ph, ow = 2 * iw + pw;
+                        const size_t idx = ((((size_t)n * a.OD + od) * a.OH + oh) * a.OW + ow) * a.Co + co;
+                        float v = acc[i][j][e] * sc + sh;
+                        if (a.res) v += a.res[idx];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        a.y[idx] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host dispatch
+// ---------------------------------------------------------------------------------------------
+template <int CC, int STRIDE, int TD, int TH, int TW, int BW, int WM, int WN, int MB, int NB>
+static int launch_conv(const char* name, ConvArgs a, hipStream_t s) {
+    a.ntd = cdiv(a.OD, TD); a.nth = cdiv(a.OH, TH); a.ntw = cdiv(a.OW, TW);
+    a.ngroups = a.Co / (32 * WN * NB);
+    a.nbtot = a.Co / 32;
+    const size_t nblk = (size_t)a.N * a.ntd * a.nth * a.ntw * a.ngroups;
+    if (nblk == 0 || nblk > 0x7fffffffu) return fail("%s: bad grid %zu", name, nblk);
+    const double vox = (double)a.N * a.OD * a.OH * a.OW;
+    LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
+                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
+    hipLaunchKernelGGL((conv3d_k3_mfma<CC, STRIDE, TD, TH, TW, BW, WM, WN, MB, NB>), dim3((unsigned)nblk),
+                       dim3(256), 0, s, a);
+    return check_launch(name);
+}
+
+template <int CI, int TD, int TH, int TW, int BW, int WM, int WN, int MB, int NB>
+static int launch_deconv(const char* name, ConvArgs a, hipStream_t s) {
+    a.ntd = cdiv(a.D, TD); a.nth = cdiv(a.H, TH); a.ntw = cdiv(a.W, TW);
+    a.ngroups = a.Co / (32 * WN * NB);
+    a.nbtot = a.Co / 32;
+    const size_t nblk = (size_t)a.N * a.ntd * a.nth * a.ntw * a.ngroups;
+    if (nblk == 0 || nblk > 0x7fffffffu) return fail("%s: bad grid %zu", name, nblk);
+    const double ivox = (double)a.N * a.D * a.H * a.W;
+    LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * ivox,
+                   4.0 * (ivox * a.Ci + 8.0 * ivox * a.Co * (a.res ? 2 : 1)));
+    hipLaunchKernelGGL((deconv3d_k3s2_mfma<CI, TD, TH, TW, BW, WM, WN, MB, NB>), dim3((unsigned)nblk), dim3(256),
+                       0, s, a);
+    return check_launch(name);
+}
+
+// Pick the M-block shape that wastes the fewest lanes on the W axis: 1x32 voxels when OW is a multiple of
+// 32 (or large), else 2x16.
+static inline bool prefer_bw16(int ow) {
+    const int w32 = cdiv(ow, 32) * 32, w16 = cdiv(ow, 16) * 16;
+    return w16 < w32;
+}
+
+}  // namespace msnet
+
+using namespace msnet;
+
+extern "C" int msnet_conv3d_k3(const float* x, const float* wpk, const float* scale, const float* shift,
+                               const float* residual, float* y, int N, int D, int H, int W, int Ci, int Co,
+                               int stride, int relu, msnet_stream_t stream) {
+    if (!x || !wpk || !y) return fail("msnet_conv3d_k3: null pointer");
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_conv3d_k3: empty input %dx%dx%dx%d", N, D, H, W);
+    if (stride != 1 && stride != 2) return fail("msnet_conv3d_k3: stride %d not in {1,2}", stride);
+    if (Co % 32 != 0 || Co <= 0) return fail("msnet_conv3d_k3: Co=%d must be a positive multiple of 32", Co);
+    if (!(Ci == 8 || (Ci > 0 && Ci % 16 == 0))) return fail("msnet_conv3d_k3: Ci=%d must be 8 or a multiple of 16", Ci);
+    ConvArgs a{};
+    a.x = x; a.wpk = reinterpret_cast<const f32x4*>(wpk); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu;
+    a.OD = (D - 1) / stride + 1; a.OH = (H - 1) / stride + 1; a.OW = (W - 1) / stride + 1;
+    hipStream_t s = (hipStream_t)stream;
+    const bool two = (Co % 64 == 0);
+    const bool b16 = prefer_bw16(a.OW);
+    if (stride == 1) {
+        if (Ci == 8) {
+            //            CC S TD TH TW  BW WM WN MB NB
+            if (two) return launch_conv<8, 1, 2, 8, 32, 32, 4, 1, 4, 2>("conv3d_s1_c8", a, s);
+            return launch_conv<8, 1, 4, 8, 32, 32, 4, 1, 8, 1>("conv3d_s1_c8", a, s);
+        }
+        if (Ci % 32 == 0) {
+            if (b16) {
+                if (two) return launch_conv<32, 1, 2, 8, 16, 16, 4, 1, 2, 2>("conv3d_s1", a, s);
+                return launch_conv<32, 1, 2, 8, 16, 16, 4, 1, 2, 1>("conv3d_s1", a, s);
+            }
+            if (two) return launch_conv<32, 1, 2, 4, 32, 32, 4, 1, 2, 2>("conv3d_s1", a, s);
+            return launch_conv<32, 1, 2, 4, 32, 32, 4, 1, 2, 1>("conv3d_s1", a, s);
+        }
+        if (two) return launch_conv<16, 1, 2, 8, 16, 16, 4, 1, 2, 2>("conv3d_s1", a, s);
+        return launch_conv<16, 1, 2, 8, 16, 16, 4, 1, 2, 1>("conv3d_s1", a, s);
+    }
+    // stride 2: the input halo tile is (2T+1)^3 voxels, so stage 16 channels at a time and keep the tile at
+    // 2x4x16 outputs (4 M-blocks); with Co >= 64 the four waves split 2 (M) x 2 (N).
+    if (Ci % 16 != 0) return fail("msnet_conv3d_k3: stride 2 needs Ci %% 16 == 0 (got %d)", Ci);
+    if (two) return launch_conv<16, 2, 2, 4, 16, 16, 2, 2, 2, 1>("conv3d_s2", a, s);
+    return launch_conv<16, 2, 2, 4, 16, 16, 4, 1, 1, 1>("conv3d_s2", a, s);
+}
+
+extern "C" int msnet_deconv3d_k3s2(const float* x, const float* wpk, const float* scale, const float* shift,
+                                   const float* residual, float* y, int N, int D, int H, int W, int Ci, int Co,
+                                   int relu, msnet_stream_t stream) {
+    if (!x || !wpk || !y) return fail("msnet_deconv3d_k3s2: null pointer");
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_deconv3d_k3s2: empty input");
+    if (Co % 32 != 0 || Co <= 0) return fail("msnet_deconv3d_k3s2: Co=%d must be a positive multiple of 32", Co);
+    ConvArgs a{};
+    a.x = x; a.wpk = reinterpret_cast<const f32x4*>(wpk); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu;
+    a.OD = 2 * D; a.OH = 2 * H; a.OW = 2 * W;
+    hipStream_t s = (hipStream_t)stream;
+    const bool two = (Co % 64 == 0);
+    const bool b16 = prefer_bw16(W);
+    switch (Ci) {
+    case 32:
+        //                              CI TD TH TW  BW WM WN MB NB
+        if (b16) { if (two) return launch_deconv<32, 2, 8, 16, 16, 4, 1, 2, 2>("deconv3d", a, s);
+                   return launch_deconv<32, 2, 8, 16, 16, 4, 1, 2, 1>("deconv3d", a, s); }
+        if (two) return launch_deconv<32, 2, 4, 32, 32, 4, 1, 2, 2>("deconv3d", a, s);
+        return launch_deconv<32, 2, 4, 32, 32, 4, 1, 2, 1>("deconv3d", a, s);
+    case 64:
+        if (b16) { if (two) return launch_deconv<64, 2, 8, 16, 16, 4, 1, 2, 2>("deconv3d", a, s);
+                   return launch_deconv<64, 2, 8, 16, 16, 4, 1, 2, 1>("deconv3d", a, s); }
+        if (two) return launch_deconv<64, 2, 4, 32, 32, 4, 1, 2, 2>("deconv3d", a, s);
+        return launch_deconv<64, 2, 4, 32, 32, 4, 1, 2, 1>("deconv3d", a, s);
+    case 128:
+        if (two) return launch_deconv<128, 1, 4, 16, 16, 2, 2, 1, 1>("deconv3d", a, s);
+        return fail("msnet_deconv3d_k3s2: Ci=128 needs Co %% 64 == 0 (got %d)", Co);
+    default:
+        return fail("msnet_deconv3d_k3s2: Ci=%d not in {32,64,128}", Ci);
+    }
+}

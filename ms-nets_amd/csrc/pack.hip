@@ -1,0 +1,115 @@
+// Weight repacking into MFMA lane order, and NCDHW <-> NDHWC layout changes at the module boundary.
+#include "common.h"
+
+namespace msnet {
+
+// packed[((tap*Ci/8 + ci8)*Co/32 + nb)*64 + lane][t] = W[co = nb*32 + (lane&31)][ci = ci8*8 + 4*(lane>>5) + t][tap]
+// (see the operand-map comment at the top of conv3d.hip).  TRANSPOSED selects the ConvTranspose3d
+// weight layout [Ci][Co][27] instead of Conv3d's [Co][Ci][27].
+template <bool TRANSPOSED>
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ out, int Ci, int Co) {
+    const size_t total = (size_t)27 * Ci * Co;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        size_t i = o;
+        const int t = i & 3; i >>= 2;
+        const int lane = i & 63; i >>= 6;
+        const int nbtot = Co >> 5, nci8 = Ci >> 3;
+        const int nb = i % nbtot; i /= nbtot;
+        const int ci8 = i % nci8;
+        const int tap = (int)(i / nci8);
+        const int co = nb * 32 + (lane & 31);
+        const int ci = ci8 * 8 + 4 * (lane >> 5) + t;
+        const size_t src = TRANSPOSED ? ((size_t)ci * Co + co) * 27 + tap : ((size_t)co * Ci + ci) * 27 + tap;
+        out[o] = w[src];
+    }
+}
+
+// [N][C][S] -> [N][S][C] (S = D*H*W).  One workgroup moves 256 voxels x C channels through LDS so both the
+// reads (along S) and the writes (C-contiguous runs) are coalesced.
+__global__ __launch_bounds__(256) void ncs_to_nsc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         int C, long S) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][LS], LS chosen bank-conflict-free
+    const int LS = 256 + (C < 32 ? 32 / C : 1);
+    const long s0 = (long)blockIdx.x * 256;
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int cnt = (int)((S - s0 < 256) ? (S - s0) : 256);
+    const float* sp = src + (size_t)n * C * S + s0;
+    for (int c = 0; c < C; ++c)
+        if (tid < cnt) tile[c * LS + tid] = sp[(size_t)c * S + tid];
+    __syncthreads();
+    float* dp = dst + ((size_t)n * S + s0) * C;
+    const int total = cnt * C;
+    for (int k = tid; k < total; k += 256) dp[k] = tile[(k % C) * LS + k / C];
+}
+
+__global__ __launch_bounds__(256) void nsc_to_ncs_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                         int C, long S) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][LS], LS chosen bank-conflict-free
+    const int LS = 256 + (C < 32 ? 32 / C : 1);
+    const long s0 = (long)blockIdx.x * 256;
+    const int n = blockIdx.y;
+    const int tid = threadIdx.x;
+    const int cnt = (int)((S - s0 < 256) ? (S - s0) : 256);
+    const float* sp = src + ((size_t)n * S + s0) * C;
+    const int total = cnt * C;
+    for (int k = tid; k < total; k += 256) tile[(k % C) * LS + k / C] = sp[k];
+    __syncthreads();
+    float* dp = dst + (size_t)n * C * S + s0;
+    for (int c = 0; c < C; ++c)
+        if (tid < cnt) dp[(size_t)c * S + tid] = tile[c * LS + tid];
+}
+
+}  // namespace msnet
+
+using namespace msnet;
+
+extern "C" size_t msnet_packed_weight_floats(int Ci, int Co) { return (size_t)27 * Ci * Co; }
+
+static int pack_common(bool transposed, const float* w, float* packed, int Ci, int Co, msnet_stream_t stream) {
+    if (!w || !packed) return fail("msnet_pack_*_weight: null pointer");
+    if (Ci <= 0 || Ci % 8 != 0) return fail("msnet_pack_*_weight: Ci=%d must be a positive multiple of 8", Ci);
+    if (Co <= 0 || Co % 32 != 0) return fail("msnet_pack_*_weight: Co=%d must be a positive multiple of 32", Co);
+    const size_t total = (size_t)27 * Ci * Co;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope ls("pack_weight", s, 0, 8.0 * total);
+    if (transposed) hipLaunchKernelGGL(pack_weight_kernel<true>, dim3(blocks), dim3(256), 0, s, w, packed, Ci, Co);
+    else            hipLaunchKernelGGL(pack_weight_kernel<false>, dim3(blocks), dim3(256), 0, s, w, packed, Ci, Co);
+    return check_launch("pack_weight");
+}
+
+extern "C" int msnet_pack_conv_weight(const float* w, float* packed, int Ci, int Co, msnet_stream_t stream) {
+    return pack_common(false, w, packed, Ci, Co, stream);
+}
+extern "C" int msnet_pack_deconv_weight(const float* w, float* packed, int Ci, int Co, msnet_stream_t stream) {
+    return pack_common(true, w, packed, Ci, Co, stream);
+}
+
+static int layout_common(bool to_cl, const float* src, float* dst, int N, int C, int D, int H, int W,
+                         msnet_stream_t stream) {
+    if (!src || !dst) return fail("msnet layout: null pointer");
+    if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet layout: empty tensor");
+    if (C > 128) return fail("msnet layout: C=%d > 128 unsupported", C);
+    if (N > 65535) return fail("msnet layout: N=%d > 65535", N);
+    const long S = (long)D * H * W;
+    const size_t lds = (size_t)C * (256 + (C < 32 ? 32 / C : 1)) * sizeof(float);
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid((unsigned)((S + 255) / 256), (unsigned)N);
+    LaunchScope ls(to_cl ? "ncdhw_to_ndhwc" : "ndhwc_to_ncdhw", s, 0, 8.0 * N * C * (double)S);
+    if (to_cl) {
+        if (lds > 65536) hipFuncSetAttribute((const void*)ncs_to_nsc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(ncs_to_nsc_kernel, grid, dim3(256), lds, s, src, dst, C, S);
+    } else {
+        if (lds > 65536) hipFuncSetAttribute((const void*)nsc_to_ncs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(nsc_to_ncs_kernel, grid, dim3(256), lds, s, src, dst, C, S);
+    }
+    return check_launch("msnet layout");
+}
+
+extern "C" int msnet_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, int D, int H, int W, msnet_stream_t stream) {
+    return layout_common(true, src, dst, N, C, D, H, W, stream);
+}
+extern "C" int msnet_ndhwc_to_ncdhw(const float* src, float* dst, int N, int C, int D, int H, int W, msnet_stream_t stream) {
+    return layout_common(false, src, dst, N, C, D, H, W, stream);
+}

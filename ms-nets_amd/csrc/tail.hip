@@ -1,0 +1,372 @@
+// Single-output-channel heads and the soft-argmin tails.  All of these are HBM-bound (1 output channel,
+// arithmetic intensity ~11 flop/B), so they run on the VALU with the weights in SGPRs, stream
+// the input one depth slice at a time through LDS, and never materialise the [D][H][W] logit volume.
+//
+//   msnet_deconv5_softargmin  : gcnet_3dcnn.py:124-141  (ConvTranspose3d 32->1 + softmax + sum d*p)
+//   msnet_conv3d_k3_cout1     : psmnet_3dcnn.py:112-122 (classif*.2, Conv3d 32->1) and :146-147 (+ cost_{k-1})
+//   msnet_trilinear_softargmin: psmnet_3dcnn.py:167-174 (F.interpolate trilinear align_corners + softmax + sum)
+//   msnet_softargmin          : gcnet_3dcnn.py:126-141 on an explicit logit volume
+//   msnet_deconv3d_cout1      : gcnet_3dcnn.py:88-92 un-fused (stride 2, or stride 4 / output_padding 3)
+#include "common.h"
+
+namespace msnet {
+
+// Online softmax state for sum_d d * softmax(x)_d.
+struct SoftArg {
+    float m, s, t;
+    __device__ __forceinline__ void init() { m = -INFINITY; s = 0.f; t = 0.f; }
+    __device__ __forceinline__ void push(float x, float d) {
+        const float mn = fmaxf(m, x);
+        const float a = __expf(m - mn), e = __expf(x - mn);
+        s = s * a + e;
+        t = t * a + d * e;
+        m = mn;
+    }
+    __device__ __forceinline__ void push2(float x0, float d0, float x1, float d1) {
+        const float mn = fmaxf(m, fmaxf(x0, x1));
+        const float a = __expf(m - mn), e0 = __expf(x0 - mn), e1 = __expf(x1 - mn);
+        s = s * a + e0 + e1;
+        t = t * a + d0 * e0 + d1 * e1;
+        m = mn;
+    }
+    __device__ __forceinline__ float result() const { return t / s; }
+};
+
+// Stage one depth slice (IH x IW voxels x CI channels, origin (h0,w0)) of an NDHWC tensor into LDS [pos][CI+4].
+template <int CI, int IH, int IW>
+__device__ __forceinline__ void stage_slice(float* lds, const float* __restrict__ x, size_t slice_base, int H, int W,
+                                            int h0, int w0, int tid) {
+    constexpr int PS = CI + 4, V = CI / 4, NSLOT = IH * IW * V, U = 4;
+    for (int base = 0; base < NSLOT; base += 256 * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int slot = base + u * 256 + tid;
+            const int pos = slot / V, c4 = slot % V;
+            const int gh = h0 + pos / IW, gw = w0 + pos % IW;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (slot < NSLOT && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+                v[u] = *reinterpret_cast<const f32x4*>(x + (slice_base + (size_t)gh * W + gw) * CI + c4 * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int slot = base + u * 256 + tid;
+            if (slot < NSLOT) *reinterpret_cast<f32x4*>(lds + (slot / V) * PS + (slot % V) * 4) = v[u];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// deconv5 + softmax + disparity regression.  Thread = one input column (h', w'), i.e. the 2x2 output
+// pixels (2h'+ph, 2w'+pw); it walks the D' input slices once.  With o = 2i - 1 + k per axis:
+//   logit[2P-1] = sum_{k=2 taps of slice P-1} + sum_{k=0 taps of slice P}   (odd output slice)
+//   logit[2P]   = sum_{k=1 taps of slice P}                                  (even output slice)
+// so each staged slice yields three partial sums per output pixel (kd = 0,1,2); the kd=2 partial is
+// carried to the next slice.  27*CI MACs per input voxel, exactly the dense definition.
+// ---------------------------------------------------------------------------------------------
+template <int CI, bool WRITE_LOGITS>
+__global__ __launch_bounds__(256) void deconv5_tail_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           float bias, float* __restrict__ out, int N, int D, int H,
+                                                           int W, int nth, int ntw) {
+    constexpr int TH = 8, TW = 32, IH = TH + 1, IW = TW + 1, PS = CI + 4;
+    __shared__ __attribute__((aligned(16))) float lds[IH * IW * PS];
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw = bid % ntw; bid /= ntw;
+    const int th = bid % nth;
+    const int n = bid / nth;
+    const int tid = threadIdx.x, lh = tid >> 5, lw = tid & 31;
+    const int h0 = th * TH, w0 = tw * TW, h = h0 + lh, wq = w0 + lw;
+    const int OH = 2 * H, OW = 2 * W, OD = 2 * D;
+
+    SoftArg sa[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) sa[c].init();
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool live = (h < H) && (wq < W);
+
+    for (int P = 0; P <= D; ++P) {
+        float p[3][4];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[kd][c] = 0.f;
+        if (P < D) {
+            __syncthreads();
+            stage_slice<CI, IH, IW>(lds, x, ((size_t)n * D + P) * H * W, H, W, h0, w0, tid);
+            __syncthreads();
+#pragma unroll
+            for (int c4 = 0; c4 < CI / 4; ++c4) {
+                f32x4 xv[2][2];
+#pragma unroll
+                for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                    for (int dw = 0; dw < 2; ++dw)
+                        xv[dh][dw] = *reinterpret_cast<const f32x4*>(lds + ((lh + dh) * IW + lw + dw) * PS + c4 * 4);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float* wc = w + (c4 * 4 + cc) * 27;
+#pragma unroll
+                    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                            for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                                for (int dh = 0; dh <= ph; ++dh)
+#pragma unroll
+                                    for (int dw = 0; dw <= pw; ++dw) {
+                                        const int kh = ph ? (dh ? 0 : 2) : 1;
+                                        const int kw = pw ? (dw ? 0 : 2) : 1;
+                                        p[kd][ph * 2 + pw] += xv[dh][dw][cc] * wc[kd * 9 + kh * 3 + kw];
+                                    }
+                }
+            }
+        }
+        // output slices finished by this input slice
+        if (WRITE_LOGITS) {
+            if (live) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const size_t pix = (size_t)(2 * h + (c >> 1)) * OW + (2 * wq + (c & 1));
+                    if (P >= 1) out[((size_t)n * OD + (2 * P - 1)) * OH * OW + pix] = carry[c] + p[0][c] + bias;
+                    if (P < D)  out[((size_t)n * OD + 2 * P) * OH * OW + pix] = p[1][c] + bias;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float lo = carry[c] + p[0][c] + bias, hi = p[1][c] + bias;
+                if (P >= 1 && P < D) sa[c].push2(lo, (float)(2 * P - 1), hi, (float)(2 * P));
+                else if (P < D)      sa[c].push(hi, (float)(2 * P));
+                else                 sa[c].push(lo, (float)(2 * P - 1));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) carry[c] = p[2][c];
+    }
+    if (!WRITE_LOGITS && live) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            out[((size_t)n * OH + (2 * h + (c >> 1))) * OW + (2 * wq + (c & 1))] = sa[c].result();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Conv3d(CI -> 1, k3, p1) head, streamed slice by slice: out[o] = sum_k x[o+k-1] w[k], so input slice P
+// adds its kd=2 partial to out[P-1] (finishing it), kd=1 to out[P] and kd=0 to out[P+1].
+// ---------------------------------------------------------------------------------------------
+template <int CI>
+__global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ add, float* __restrict__ y, int N,
+                                                         int D, int H, int W, int nth, int ntw) {
+    constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, PS = CI + 4;
+    __shared__ __attribute__((aligned(16))) float lds[IH * IW * PS];
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw = bid % ntw; bid /= ntw;
+    const int th = bid % nth;
+    const int n = bid / nth;
+    const int tid = threadIdx.x, lh = tid >> 5, lw = tid & 31;
+    const int h0 = th * TH, w0 = tw * TW, h = h0 + lh, wq = w0 + lw;
+    const bool live = (h < H) && (wq < W);
+    float r1 = 0.f, r0 = 0.f;
+    for (int P = 0; P <= D; ++P) {
+        float q[3] = {0.f, 0.f, 0.f};
+        if (P < D) {
+            __syncthreads();
+            stage_slice<CI, IH, IW>(lds, x, ((size_t)n * D + P) * H * W, H, W, h0 - 1, w0 - 1, tid);
+            __syncthreads();
+#pragma unroll
+            for (int c4 = 0; c4 < CI / 4; ++c4) {
+                f32x4 xv[3][3];
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        xv[kh][kw] = *reinterpret_cast<const f32x4*>(lds + ((lh + kh) * IW + lw + kw) * PS + c4 * 4);
+#pragma unroll
+                for (int cc = 0; cc < 4; ++cc) {
+                    const float* wc = w + (c4 * 4 + cc) * 27;
+#pragma unroll
+                    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw) q[kd] += xv[kh][kw][cc] * wc[kd * 9 + kh * 3 + kw];
+                }
+            }
+        }
+        if (P >= 1 && live) {
+            const size_t idx = (((size_t)n * D + (P - 1)) * H + h) * W + wq;
+            float v = r1 + q[2];
+            if (add) v += add[idx];
+            y[idx] = v;
+        }
+        r1 = r0 + q[1];
+        r0 = q[0];
+    }
+}
+
+// Generic gather form of ConvTranspose3d(CI -> 1, k3, stride S, p1, op S-1); test / quarter-size path only.
+__global__ void deconv_cout1_naive_kernel(const float* __restrict__ x, const float* __restrict__ w, float bias,
+                                          float* __restrict__ out, int N, int D, int H, int W, int CI, int S) {
+    const int OD = S * D, OH = S * H, OW = S * W;
+    const size_t total = (size_t)N * OD * OH * OW;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        size_t i = o;
+        const int ow = i % OW; i /= OW;
+        const int oh = i % OH; i /= OH;
+        const int od = i % OD;
+        const int n = (int)(i / OD);
+        float acc = bias;
+        for (int kd = 0; kd < 3; ++kd) {
+            const int td = od + 1 - kd;
+            if (td < 0 || td % S != 0 || td / S >= D) continue;
+            for (int kh = 0; kh < 3; ++kh) {
+                const int t2 = oh + 1 - kh;
+                if (t2 < 0 || t2 % S != 0 || t2 / S >= H) continue;
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int t3 = ow + 1 - kw;
+                    if (t3 < 0 || t3 % S != 0 || t3 / S >= W) continue;
+                    const float* xp = x + ((((size_t)n * D + td / S) * H + t2 / S) * W + t3 / S) * CI;
+                    const float* wp = w + kd * 9 + kh * 3 + kw;
+                    for (int c = 0; c < CI; ++c) acc += xp[c] * wp[c * 27];
+                }
+            }
+        }
+        out[o] = acc;
+    }
+}
+
+// softmax over D + regression on an explicit logit volume [N][D][H][W]; two passes (max, then sums) like
+// torch.softmax.
+__global__ void softargmin_kernel(const float* __restrict__ logits, float* __restrict__ disp, int N, int D, long HW) {
+    const size_t total = (size_t)N * HW;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int n = (int)(o / HW);
+        const float* p = logits + (size_t)n * D * HW + (o % HW);
+        float m = -INFINITY;
+        for (int d = 0; d < D; ++d) m = fmaxf(m, p[(size_t)d * HW]);
+        float s = 0.f, t = 0.f;
+        for (int d = 0; d < D; ++d) {
+            const float e = expf(p[(size_t)d * HW] - m);
+            s += e;
+            t += e * (float)d;
+        }
+        disp[o] = t / s;
+    }
+}
+
+// F.interpolate(cost[N][1][d][h][w], [D][H][W], 'trilinear', align_corners=True) + softmax(D) + sum d*p.
+// Source coordinate = dst * (in-1)/(out-1) (float), i1 = i0 + (i0 < in-1), as ATen's upsample_trilinear3d.
+__global__ void trilinear_softargmin_kernel(const float* __restrict__ cost, float* __restrict__ disp, int N, int d,
+                                            int h, int w, int D, int H, int W) {
+    const float sd = (D > 1) ? (float)(d - 1) / (float)(D - 1) : 0.f;
+    const float sh = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sw = (W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const size_t total = (size_t)N * H * W;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int X = o % W, Y = (o / W) % H, n = (int)(o / ((size_t)W * H));
+        const float fy = sh * Y, fx = sw * X;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+        const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float* base = cost + (size_t)n * d * h * w;
+        auto plane = [&](int z) {
+            const float* q = base + (size_t)z * h * w;
+            return ly0 * (lx0 * q[y0 * w + x0] + lx1 * q[y0 * w + x1]) + ly1 * (lx0 * q[y1 * w + x0] + lx1 * q[y1 * w + x1]);
+        };
+        SoftArg sa; sa.init();
+        int zc = 0;
+        float v0 = plane(0), v1 = plane(d > 1 ? 1 : 0);
+        for (int Z = 0; Z < D; ++Z) {
+            const float fz = sd * Z;
+            const int z0 = (int)fz;
+            const float lz1 = fz - z0, lz0 = 1.f - lz1;
+            while (zc < z0) {           // advance the two cached source slices
+                ++zc;
+                v0 = v1;
+                const int z1n = zc + (zc < d - 1);
+                v1 = (z1n == zc) ? v0 : plane(z1n);
+            }
+            sa.push(lz0 * v0 + lz1 * v1, (float)Z);
+        }
+        disp[o] = sa.result();
+    }
+}
+
+}  // namespace msnet
+
+using namespace msnet;
+
+extern "C" int msnet_softargmin(const float* logits, float* disp, int N, int D, int H, int W, msnet_stream_t stream) {
+    if (!logits || !disp) return fail("msnet_softargmin: null pointer");
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_softargmin: empty input");
+    const long HW = (long)H * W;
+    const size_t total = (size_t)N * HW;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope ls("softargmin", s, 0, 4.0 * total * (2.0 * D + 1));
+    hipLaunchKernelGGL(softargmin_kernel, dim3(blocks), dim3(256), 0, s, logits, disp, N, D, HW);
+    return check_launch("msnet_softargmin");
+}
+
+extern "C" int msnet_deconv5_softargmin(const float* x, const float* w, float bias, float* disp, int N, int D, int H,
+                                        int W, int Ci, msnet_stream_t stream) {
+    if (!x || !w || !disp) return fail("msnet_deconv5_softargmin: null pointer");
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_deconv5_softargmin: empty input");
+    if (Ci != 32) return fail("msnet_deconv5_softargmin: Ci=%d (only 32 is built)", Ci);
+    const int nth = cdiv(H, 8), ntw = cdiv(W, 32);
+    hipStream_t s = (hipStream_t)stream;
+    const double vox = (double)N * D * H * W;
+    LaunchScope ls("deconv5_softargmin", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + 4.0 * N * H * W));
+    hipLaunchKernelGGL((deconv5_tail_kernel<32, false>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, bias,
+                       disp, N, D, H, W, nth, ntw);
+    return check_launch("msnet_deconv5_softargmin");
+}
+
+extern "C" int msnet_deconv3d_cout1(const float* x, const float* w, float bias, float* logits, int N, int D, int H,
+                                    int W, int Ci, int stride, msnet_stream_t stream) {
+    if (!x || !w || !logits) return fail("msnet_deconv3d_cout1: null pointer");
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || Ci <= 0) return fail("msnet_deconv3d_cout1: empty input");
+    if (stride != 2 && stride != 4) return fail("msnet_deconv3d_cout1: stride %d not in {2,4}", stride);
+    hipStream_t s = (hipStream_t)stream;
+    const double vox = (double)N * D * H * W;
+    if (stride == 2 && Ci == 32) {
+        const int nth = cdiv(H, 8), ntw = cdiv(W, 32);
+        LaunchScope ls("deconv5_logits", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + 8.0 * vox));
+        hipLaunchKernelGGL((deconv5_tail_kernel<32, true>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w,
+                           bias, logits, N, D, H, W, nth, ntw);
+        return check_launch("msnet_deconv3d_cout1");
+    }
+    const size_t total = (size_t)vox * stride * stride * stride;
+    const int blocks = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    LaunchScope ls("deconv_cout1_naive", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + total));
+    hipLaunchKernelGGL(deconv_cout1_naive_kernel, dim3(blocks), dim3(256), 0, s, x, w, bias, logits, N, D, H, W, Ci, stride);
+    return check_launch("msnet_deconv3d_cout1");
+}
+
+extern "C" int msnet_conv3d_k3_cout1(const float* x, const float* w, const float* add, float* y, int N, int D, int H,
+                                     int W, int Ci, msnet_stream_t stream) {
+    if (!x || !w || !y) return fail("msnet_conv3d_k3_cout1: null pointer");
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_conv3d_k3_cout1: empty input");
+    if (Ci != 32) return fail("msnet_conv3d_k3_cout1: Ci=%d (only 32 is built)", Ci);
+    const int nth = cdiv(H, 8), ntw = cdiv(W, 32);
+    hipStream_t s = (hipStream_t)stream;
+    const double vox = (double)N * D * H * W;
+    LaunchScope ls("conv3d_cout1", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + vox * (add ? 2 : 1)));
+    hipLaunchKernelGGL((conv_cout1_kernel<32>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, add, y, N, D, H,
+                       W, nth, ntw);
+    return check_launch("msnet_conv3d_k3_cout1");
+}
+
+extern "C" int msnet_trilinear_softargmin(const float* cost, float* disp, int N, int d, int h, int w, int D, int H,
+                                          int W, msnet_stream_t stream) {
+    if (!cost || !disp) return fail("msnet_trilinear_softargmin: null pointer");
+    if (N <= 0 || d <= 0 || h <= 0 || w <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_trilinear_softargmin: empty input");
+    const size_t total = (size_t)N * H * W;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope ls("trilinear_softargmin", s, 0, 4.0 * ((double)N * d * h * w + total));
+    hipLaunchKernelGGL(trilinear_softargmin_kernel, dim3(blocks), dim3(256), 0, s, cost, disp, N, d, h, w, D, H, W);
+    return check_launch("msnet_trilinear_softargmin");
+}

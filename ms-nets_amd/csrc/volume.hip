@@ -1,0 +1,489 @@
+// Matching-space cost volume on the GPU: the four hand-crafted matchers, the per-pixel likelihood (AML)
+// features and the 8-channel assembly.  Replaces the CPU path
+//   /root/reference/src/cpp/matchers/matchers.cpp      census :232-353, nccNister :47-228, sadsob :356-438,
+//                                                      zsad :442-512, sobel :515-554
+//   /root/reference/src/cpp/featextract/featextract.cpp swap_axes :49-76, extract_aml_testing :415-462
+//   /root/reference/src/dataloader/cbmv_generator.py    get_costs :27-79, extract_features_left :258-308
+//
+// Built with -ffp-contract=off: zsad / sadsob / the normalisation are float32 arithmetic whose operation
+// ORDER is part of the reference's result, so nothing here may be fused into an FMA or
+// re-associated.  Integer paths (census, sobel, the NCC window sums) are exact by construction.
+// Entries the reference never writes keep its fill value RAND_MAX -> 2^31 (kSentinel).
+#include "common.h"
+
+namespace msnet {
+
+// ---------------------------------------------------------------- census -------------------------------
+// Bit b = wh*wsize + ww of pixel (y,x) is [center < window(wh,ww)]; the reference pads the 121 bits to 128
+// with always-equal lanes, so cost = popcount(L ^ R_shift) over the wsize^2 real bits.
+constexpr int kCensusWords = 8;   // up to 16x16 windows
+
+__global__ void census_transform_kernel(const uint8_t* __restrict__ img, uint32_t* __restrict__ bits, int H, int W,
+                                        int ws, int nwords) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int wc = ws / 2;
+    const int i = y - wc, j = x - wc;
+    uint32_t wd[kCensusWords];
+#pragma unroll
+    for (int k = 0; k < kCensusWords; ++k) wd[k] = 0;
+    if (i >= 0 && j >= 0 && i < H - ws && j < W - ws) {
+        const int c = img[y * W + x];
+        int b = 0;
+        for (int wh = 0; wh < ws; ++wh)
+            for (int ww = 0; ww < ws; ++ww, ++b)
+                if (c < (int)img[(i + wh) * W + j + ww]) {
+#pragma unroll
+                    for (int k = 0; k < kCensusWords; ++k)
+                        if (k == (b >> 5)) wd[k] |= 1u << (b & 31);
+                }
+    }
+    for (int k = 0; k < nwords; ++k) bits[((size_t)y * W + x) * nwords + k] = wd[k];
+}
+
+// DMAJOR = false: out[y][x][d] (reference layout of census);  true: out[d][y][x] (fused path).
+template <bool DMAJOR>
+__global__ void census_cost_kernel(const uint32_t* __restrict__ lb, const uint32_t* __restrict__ rb,
+                                   float* __restrict__ out, int H, int W, int nd, int ws, int nwords) {
+    const int wc = ws / 2;
+    const size_t total = (size_t)H * W * nd;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        int d, x, y;
+        if (DMAJOR) { x = o % W; y = (o / W) % H; d = (int)(o / ((size_t)W * H)); }
+        else        { d = o % nd; x = (o / nd) % W; y = (int)(o / ((size_t)nd * W)); }
+        const int i = y - wc, j = x - wc;
+        float v = kSentinel;
+        if (i >= 0 && j >= 0 && i < H - ws && j < W - ws && d <= j) {
+            const uint32_t* a = lb + ((size_t)y * W + x) * nwords;
+            const uint32_t* b = rb + ((size_t)y * W + x - d) * nwords;
+            int cnt = 0;
+            for (int k = 0; k < nwords; ++k) cnt += __popc(a[k] ^ b[k]);
+            v = (float)cnt;
+        }
+        out[o] = v;
+    }
+}
+
+// ---------------------------------------------------------------- sobel --------------------------------
+__global__ void sobel_kernel(const uint8_t* __restrict__ img, float* __restrict__ out, int H, int W) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const int i = y - 1, j = x - 1;
+    float v = 0.f;
+    if (i >= 0 && j >= 0 && i < H - 3 && j < W - 3) {
+        const uint8_t* p = img + i * W + j;
+        const int s = -(int)p[0] + (int)p[2] - 2 * (int)p[W] + 2 * (int)p[W + 2] - (int)p[2 * W] + (int)p[2 * W + 2];
+        v = (float)s;
+    }
+    out[y * W + x] = v;
+}
+
+// ---------------------------------------------------------------- NCC ----------------------------------
+// All window sums are exact integers (the reference's u32/u64/double integral images are exact too), so
+// direct summation gives the same values; only 1/sqrt and the two final multiplies round, in double, in
+// the reference's order:  tmp = ((-(double)(n*lD - Al*Ar)) * Cl) * Cr;  cost = (float)tmp.
+__global__ void ncc_kernel(const uint8_t* __restrict__ l, const uint8_t* __restrict__ r, float* __restrict__ out,
+                           int H, int W, int nd, int ws) {
+    const int wc = ws / 2, sq = ws * ws;
+    const size_t total = (size_t)nd * H * W;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int x = o % W, y = (o / W) % H, d = (int)(o / ((size_t)W * H));
+        const int i = y - wc, j = x - wc;
+        float v = kSentinel;
+        if (i >= 0 && j >= d && i < H - ws && j < W - ws) {
+            unsigned long long Al = 0, Ar = 0, Bl = 0, Br = 0, LR = 0;
+            for (int wh = 0; wh < ws; ++wh) {
+                const uint8_t* lp = l + (i + wh) * W + j;
+                const uint8_t* rp = r + (i + wh) * W + j - d;
+                for (int ww = 0; ww < ws; ++ww) {
+                    const unsigned a = lp[ww], b = rp[ww];
+                    Al += a; Ar += b; Bl += a * a; Br += b * b; LR += a * b;
+                }
+            }
+            const double Cl = 1.0 / sqrt((double)((unsigned long long)sq * Bl) - (double)Al * (double)Al);
+            const double Cr = 1.0 / sqrt((double)((unsigned long long)sq * Br) - (double)Ar * (double)Ar);
+            if (isfinite(Cl) && isfinite(Cr)) {
+                const double num = (double)sq * (double)LR - (double)(Al * Ar);
+                double t = -num;
+                t = t * Cl;
+                t = t * Cr;
+                v = (float)t;
+            } else {
+                v = 1.f;
+            }
+        }
+        out[o] = v;
+    }
+}
+
+// ---------------------------------------------------------------- ZSAD ---------------------------------
+__device__ __forceinline__ float window_mean(const uint8_t* __restrict__ p, int W, int ws) {
+    float s = 0.f;   // sequential float sum of <= 256 bytes: exact
+    for (int wh = 0; wh < ws; ++wh)
+        for (int ww = 0; ww < ws; ++ww) s += (float)p[wh * W + ww];
+    return s / (float)(ws * ws);
+}
+
+__global__ void zsad_kernel(const uint8_t* __restrict__ l, const uint8_t* __restrict__ r, float* __restrict__ out,
+                            int H, int W, int nd, int ws) {
+    const int wc = ws / 2;
+    const size_t total = (size_t)nd * H * W;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int x = o % W, y = (o / W) % H, d = (int)(o / ((size_t)W * H));
+        const int i = y - wc, j = x - wc;
+        float v = kSentinel;
+        if (i >= 0 && j >= d && i < H - ws && j < W - ws) {
+            const uint8_t* lp = l + i * W + j;
+            const uint8_t* rp = r + i * W + j - d;
+            const float ml = window_mean(lp, W, ws), mr = window_mean(rp, W, ws);
+            float acc = 0.f;
+            for (int wh = 0; wh < ws; ++wh)
+                for (int ww = 0; ww < ws; ++ww) {
+                    float t = (float)lp[wh * W + ww] - ml;
+                    t = t - (float)rp[wh * W + ww];
+                    t = t + mr;
+                    acc = acc + fabsf(t);
+                }
+            v = acc;
+        }
+        out[o] = v;
+    }
+}
+
+// ---------------------------------------------------------------- SAD of Sobel -------------------------
+// The reference builds, per disparity, a FLOAT32 integral image of |SL - SR_shift| by a sequential vertical
+// pass followed by a sequential horizontal pass; values exceed 2^24 so the rounding depends on that order
+// and it is reproduced literally: one thread owns one column (pass V) or one row (pass H) and adds in the
+// same sequence.  ws layout: [nd][H+1][W+1].
+__global__ void sadsob_vertical_kernel(const float* __restrict__ sl, const float* __restrict__ sr, float* __restrict__ ws,
+                                       int H, int W, int nd) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;   // integral column 0..W
+    const int d = blockIdx.y;
+    if (c > W) return;
+    float* col = ws + (size_t)d * (H + 1) * (W + 1) + c;
+    col[0] = 0.f;
+    const int j = c - 1;                                    // image column
+    if (j < d) {                                            // columns the reference leaves at zero
+        for (int i = 1; i <= H; ++i) col[(size_t)i * (W + 1)] = 0.f;
+        return;
+    }
+    float run = 0.f;
+    for (int i = 1; i <= H; ++i) {
+        const float a = fabsf(sl[(i - 1) * W + j] - sr[(i - 1) * W + j - d]);
+        run = a + run;
+        col[(size_t)i * (W + 1)] = run;
+    }
+}
+
+// One wave scans 64 rows; column tiles of 64 go through LDS so global traffic stays coalesced.
+__global__ __launch_bounds__(64) void sadsob_horizontal_kernel(float* __restrict__ ws, int H, int W, int nd) {
+    __shared__ float tile[64][65];
+    const int lane = threadIdx.x;
+    const int row0 = blockIdx.x * 64;           // integral rows 0..H
+    const int d = blockIdx.y;
+    float* base = ws + (size_t)d * (H + 1) * (W + 1);
+    const int nrows = min(64, H + 1 - row0);
+    float run = 0.f;                            // slice[row][d] == 0
+    for (int c0 = d + 1; c0 <= W; c0 += 64) {
+        const int ncols = min(64, W + 1 - c0);
+        for (int rr = 0; rr < nrows; ++rr)
+            if (lane < ncols) tile[rr][lane] = base[(size_t)(row0 + rr) * (W + 1) + c0 + lane];
+        __syncthreads();
+        if (lane < nrows)
+            for (int k = 0; k < ncols; ++k) {
+                run = tile[lane][k] + run;
+                tile[lane][k] = run;
+            }
+        __syncthreads();
+        for (int rr = 0; rr < nrows; ++rr)
+            if (lane < ncols) base[(size_t)(row0 + rr) * (W + 1) + c0 + lane] = tile[rr][lane];
+        __syncthreads();
+    }
+}
+
+__global__ void sadsob_box_kernel(const float* __restrict__ ws, float* __restrict__ out, int H, int W, int nd, int wsz) {
+    const int wc = wsz / 2;
+    const size_t total = (size_t)nd * H * W;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int x = o % W, y = (o / W) % H, d = (int)(o / ((size_t)W * H));
+        const int i = y - wc, j = x - wc;
+        float v = kSentinel;
+        if (i >= 0 && j >= d && i < H - wsz && j < W - wsz) {
+            const float* s = ws + (size_t)d * (H + 1) * (W + 1);
+            const float* t = s + (size_t)i * (W + 1);
+            const float* b = s + (size_t)(i + wsz) * (W + 1);
+            float r = b[j + wsz] - b[j];
+            r = r - t[j + wsz];
+            r = r + t[j];
+            v = r;
+        }
+        out[o] = v;
+    }
+}
+
+// ---------------------------------------------------------------- swap_axes ----------------------------
+// [D][S] -> [S][D] (S = H*W) through a 64x64 LDS tile.
+__global__ __launch_bounds__(256) void swap_axes_kernel(const float* __restrict__ in, float* __restrict__ out, int D, long S) {
+    __shared__ float tile[64][65];
+    const long s0 = (long)blockIdx.x * 64;
+    const int d0 = blockIdx.y * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int k = ty; k < 64; k += 4)
+        if (d0 + k < D && s0 + tx < S) tile[k][tx] = in[(size_t)(d0 + k) * S + s0 + tx];
+    __syncthreads();
+    for (int k = ty; k < 64; k += 4)
+        if (s0 + k < S && d0 + tx < D) out[(size_t)(s0 + k) * D + d0 + tx] = tile[tx][k];
+}
+
+// ---------------------------------------------------------------- AML ----------------------------------
+// extract_aml_testing: per row of D costs, m = min; den = sum_k expf(-((c_k-m)^2)/sigma) accumulated
+// sequentially in float32; out_k = expf(-((c_k-m)^2)/sigma)/den, or 0 for an all-sentinel row.
+__device__ __forceinline__ float aml_term(float c, float m, float sigma) {
+    const float num = c - m;
+    float q = num * num;
+    q = q / sigma;
+    return expf(-q);
+}
+
+// vol/out [P][D]; 64 rows per wave staged through LDS (row stride D+1) so global accesses are coalesced.
+__global__ __launch_bounds__(64) void aml_rows_kernel(const float* __restrict__ vol, float* __restrict__ out, long P, int D,
+                                                      float sigma) {
+    extern __shared__ float rows[];   // [64][D+1]
+    const int lane = threadIdx.x;
+    const long p0 = (long)blockIdx.x * 64;
+    const int n = (int)((P - p0 < 64) ? (P - p0) : 64);
+    const int LS = D + 1;
+    const size_t base = (size_t)p0 * D;
+    for (int k = lane; k < n * D; k += 64) rows[(k / D) * LS + k % D] = vol[base + k];
+    __syncthreads();
+    if (lane < n) {
+        float* rp = rows + lane * LS;
+        float m = kSentinel;
+        for (int k = 0; k < D; ++k) if (rp[k] < m) m = rp[k];
+        float den = 0.f;
+        for (int k = 0; k < D; ++k) den += aml_term(rp[k], m, sigma);
+        for (int k = 0; k < D; ++k) rp[k] = (m == kSentinel) ? 0.f : aml_term(rp[k], m, sigma) / den;
+    }
+    __syncthreads();
+    for (int k = lane; k < n * D; k += 64) out[base + k] = rows[(k / D) * LS + k % D];
+}
+
+// ---------------------------------------------------------------- assembly -----------------------------
+// extract_features_left on d-major raw costs [nd][Hb][Wb]: crop the border, write
+//   out[ch][d][y][x]    = normalised cost     (ch 0..3 = census, ncc, sobel-SAD, zsad)
+//   out[4+ch][d][y][x]  = AML(raw cost, sigma_ch)
+// Thread = one pixel, lanes = consecutive x, so every access is a coalesced 256-byte run per d.
+struct AssembleArgs {
+    const float* raw[4];
+    float sigma[4];
+    float* out;
+    int Hb, Wb, nd, bh, bw, Hc, Wc;
+};
+
+__device__ __forceinline__ float normalise_cost(int ch, float c) {
+    switch (ch) {
+    case 0: return fminf(fmaxf(c, 0.f), 120.f) / 120.f;                  // cbmv_generator.py:283
+    case 1: { float t = fminf(fmaxf(c, -1.f), 1.f); t = 1.f + t; return t / 2.f; }   // :285
+    default: return fminf(fmaxf(c, 0.f), 8192.f) / 8192.f;               // :286-287
+    }
+}
+
+__global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
+    const int ch = blockIdx.z;
+    const int y = blockIdx.y;
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= a.Wc) return;
+    const size_t plane_in = (size_t)a.Hb * a.Wb;
+    const float* src = a.raw[ch] + (size_t)(y + a.bh) * a.Wb + (x + a.bw);
+    const size_t plane_out = (size_t)a.Hc * a.Wc;
+    float* o_cost = a.out + ((size_t)ch * a.nd) * plane_out + (size_t)y * a.Wc + x;
+    float* o_aml = a.out + ((size_t)(4 + ch) * a.nd) * plane_out + (size_t)y * a.Wc + x;
+    const float sigma = a.sigma[ch];
+    float m = kSentinel;
+    for (int d = 0; d < a.nd; ++d) { const float c = src[d * plane_in]; if (c < m) m = c; }
+    float den = 0.f;
+    for (int d = 0; d < a.nd; ++d) den += aml_term(src[d * plane_in], m, sigma);
+    for (int d = 0; d < a.nd; ++d) {
+        const float c = src[d * plane_in];
+        o_cost[d * plane_out] = normalise_cost(ch, c);
+        o_aml[d * plane_out] = (m == kSentinel) ? 0.f : aml_term(c, m, sigma) / den;
+    }
+}
+
+static inline int grid1d(size_t total, int cap = 16384) {
+    const size_t b = (total + 255) / 256;
+    return (int)(b < (size_t)cap ? (b ? b : 1) : cap);
+}
+
+static int check_img(const char* fn, const void* a, const void* b, const void* c, int H, int W, int nd, int ws) {
+    if (!a || !b || !c) return fail("%s: null pointer", fn);
+    if (H <= 0 || W <= 0) return fail("%s: empty image %dx%d", fn, H, W);
+    if (nd <= 0) return fail("%s: ndisp=%d must be positive", fn, nd);
+    if (ws <= 0 || ws > 15 || (ws & 1) == 0) return fail("%s: wsize=%d must be odd and <= 15", fn, ws);
+    return 0;
+}
+
+static int census_impl(const uint8_t* l, const uint8_t* r, float* out, uint32_t* bits, int H, int W, int nd, int ws,
+                       bool dmajor, hipStream_t s) {
+    const int nwords = (ws * ws + 31) / 32;
+    uint32_t* lb = bits;
+    uint32_t* rb = bits + (size_t)H * W * nwords;
+    dim3 g2(cdiv(W, 64), H);
+    {
+        LaunchScope ls("census_transform", s, 0, 2.0 * H * W * (1 + 4.0 * nwords));
+        hipLaunchKernelGGL(census_transform_kernel, g2, dim3(64), 0, s, l, lb, H, W, ws, nwords);
+        hipLaunchKernelGGL(census_transform_kernel, g2, dim3(64), 0, s, r, rb, H, W, ws, nwords);
+    }
+    const size_t total = (size_t)H * W * nd;
+    LaunchScope ls("census_cost", s, 0, 4.0 * total);
+    if (dmajor) hipLaunchKernelGGL(census_cost_kernel<true>, dim3(grid1d(total)), dim3(256), 0, s, lb, rb, out, H, W, nd, ws, nwords);
+    else        hipLaunchKernelGGL(census_cost_kernel<false>, dim3(grid1d(total)), dim3(256), 0, s, lb, rb, out, H, W, nd, ws, nwords);
+    return check_launch("census");
+}
+
+static int sadsob_impl(const float* sl, const float* sr, float* out, float* ws, int H, int W, int nd, int wsz, hipStream_t s) {
+    {
+        LaunchScope ls("sadsob_vertical", s, 0, 4.0 * nd * (double)(H + 1) * (W + 1));
+        hipLaunchKernelGGL(sadsob_vertical_kernel, dim3(cdiv(W + 1, 64), nd), dim3(64), 0, s, sl, sr, ws, H, W, nd);
+    }
+    {
+        LaunchScope ls("sadsob_horizontal", s, 0, 8.0 * nd * (double)(H + 1) * (W + 1));
+        hipLaunchKernelGGL(sadsob_horizontal_kernel, dim3(cdiv(H + 1, 64), nd), dim3(64), 0, s, ws, H, W, nd);
+    }
+    const size_t total = (size_t)nd * H * W;
+    LaunchScope ls("sadsob_box", s, 0, 8.0 * total);
+    hipLaunchKernelGGL(sadsob_box_kernel, dim3(grid1d(total)), dim3(256), 0, s, ws, out, H, W, nd, wsz);
+    return check_launch("sadsob");
+}
+
+}  // namespace msnet
+
+using namespace msnet;
+
+extern "C" size_t msnet_census_workspace_bytes(int H, int W, int wsize) {
+    if (H <= 0 || W <= 0 || wsize <= 0) return 0;
+    return (size_t)2 * H * W * ((wsize * wsize + 31) / 32) * sizeof(uint32_t);
+}
+
+extern "C" int msnet_census(const uint8_t* l, const uint8_t* r, float* out, void* workspace, int H, int W, int ndisp,
+                            int wsize, msnet_stream_t stream) {
+    if (int e = check_img("msnet_census", l, r, out, H, W, ndisp, wsize)) return e;
+    if (!workspace) return fail("msnet_census: null workspace");
+    return census_impl(l, r, out, (uint32_t*)workspace, H, W, ndisp, wsize, false, (hipStream_t)stream);
+}
+
+extern "C" int msnet_ncc(const uint8_t* l, const uint8_t* r, float* out, int H, int W, int ndisp, int wsize,
+                         msnet_stream_t stream) {
+    if (int e = check_img("msnet_ncc", l, r, out, H, W, ndisp, wsize)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)ndisp * H * W;
+    LaunchScope ls("ncc", s, 0, 4.0 * total);
+    hipLaunchKernelGGL(ncc_kernel, dim3(grid1d(total)), dim3(256), 0, s, l, r, out, H, W, ndisp, wsize);
+    return check_launch("msnet_ncc");
+}
+
+extern "C" int msnet_zsad(const uint8_t* l, const uint8_t* r, float* out, int H, int W, int ndisp, int wsize,
+                          msnet_stream_t stream) {
+    if (int e = check_img("msnet_zsad", l, r, out, H, W, ndisp, wsize)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)ndisp * H * W;
+    LaunchScope ls("zsad", s, 0, 4.0 * total);
+    hipLaunchKernelGGL(zsad_kernel, dim3(grid1d(total)), dim3(256), 0, s, l, r, out, H, W, ndisp, wsize);
+    return check_launch("msnet_zsad");
+}
+
+extern "C" int msnet_sobel(const uint8_t* img, float* out, int H, int W, msnet_stream_t stream) {
+    if (!img || !out) return fail("msnet_sobel: null pointer");
+    if (H <= 0 || W <= 0) return fail("msnet_sobel: empty image");
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope ls("sobel", s, 0, 5.0 * H * W);
+    hipLaunchKernelGGL(sobel_kernel, dim3(cdiv(W, 64), H), dim3(64), 0, s, img, out, H, W);
+    return check_launch("msnet_sobel");
+}
+
+extern "C" size_t msnet_sadsob_workspace_bytes(int H, int W, int ndisp) {
+    if (H <= 0 || W <= 0 || ndisp <= 0) return 0;
+    return (size_t)ndisp * (H + 1) * (W + 1) * sizeof(float);
+}
+
+extern "C" int msnet_sadsob(const float* sl, const float* sr, float* out, void* workspace, int H, int W, int ndisp,
+                            int wsize, msnet_stream_t stream) {
+    if (int e = check_img("msnet_sadsob", sl, sr, out, H, W, ndisp, wsize)) return e;
+    if (!workspace) return fail("msnet_sadsob: null workspace");
+    return sadsob_impl(sl, sr, out, (float*)workspace, H, W, ndisp, wsize, (hipStream_t)stream);
+}
+
+extern "C" int msnet_swap_axes(const float* in, float* out, int D, int H, int W, msnet_stream_t stream) {
+    if (!in || !out) return fail("msnet_swap_axes: null pointer");
+    if (D <= 0 || H <= 0 || W <= 0) return fail("msnet_swap_axes: empty tensor");
+    const long S = (long)H * W;
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope ls("swap_axes", s, 0, 8.0 * D * (double)S);
+    hipLaunchKernelGGL(swap_axes_kernel, dim3((unsigned)((S + 63) / 64), cdiv(D, 64)), dim3(256), 0, s, in, out, D, S);
+    return check_launch("msnet_swap_axes");
+}
+
+extern "C" int msnet_extract_likelihood(const float* vol, float* out, long P, int D, float sigma, msnet_stream_t stream) {
+    if (!vol || !out) return fail("msnet_extract_likelihood: null pointer");
+    if (P <= 0 || D <= 0) return fail("msnet_extract_likelihood: empty volume");
+    const size_t lds = (size_t)64 * (D + 1) * sizeof(float);
+    if (lds > 160 * 1024) return fail("msnet_extract_likelihood: D=%d too large for one LDS tile", D);
+    hipStream_t s = (hipStream_t)stream;
+    if (lds > 65536) hipFuncSetAttribute((const void*)aml_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    LaunchScope ls("extract_likelihood", s, 0, 8.0 * P * (double)D);
+    hipLaunchKernelGGL(aml_rows_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), lds, s, vol, out, P, D, sigma);
+    return check_launch("msnet_extract_likelihood");
+}
+
+extern "C" void msnet_volume_default_params(msnet_volume_params* p) {
+    if (!p) return;
+    p->censw = 11; p->nccw = 3; p->sadw = 5; p->sobelw = 5;
+    p->cens_sigma = 128.f; p->ncc_sigma = 0.02f; p->sad_sigma = 20000.f;
+    p->border_h = 10; p->border_w = 10;
+}
+
+// workspace carve (floats unless noted): raw[4] each nd*Hb*Wb | sobel L,R each Hb*Wb | integral nd*(Hb+1)*(Wb+1)
+// | census bit images 2*Hb*Wb*8 u32
+extern "C" size_t msnet_build_volume_workspace_bytes(int Hb, int Wb, int ndisp) {
+    if (Hb <= 0 || Wb <= 0 || ndisp <= 0) return 0;
+    const size_t vol = (size_t)ndisp * Hb * Wb;
+    const size_t fl = 4 * vol + 2 * (size_t)Hb * Wb + (size_t)ndisp * (Hb + 1) * (Wb + 1) + 16 * (size_t)Hb * Wb;
+    return (fl * sizeof(float) + 255) & ~(size_t)255;
+}
+
+extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int ndisp,
+                                  const msnet_volume_params* pp, void* workspace, float* out, msnet_stream_t stream) {
+    msnet_volume_params p;
+    if (pp) p = *pp; else msnet_volume_default_params(&p);
+    if (!l || !r || !workspace || !out) return fail("msnet_build_volume: null pointer");
+    if (ndisp <= 0) return fail("msnet_build_volume: ndisp=%d", ndisp);
+    const int Hc = Hb - 2 * p.border_h, Wc = Wb - 2 * p.border_w;
+    if (p.border_h < 0 || p.border_w < 0 || Hc <= 0 || Wc <= 0)
+        return fail("msnet_build_volume: %dx%d image with border %dx%d leaves nothing", Hb, Wb, p.border_h, p.border_w);
+    if (int e = check_img("msnet_build_volume", l, r, out, Hb, Wb, ndisp, p.censw)) return e;
+    if (int e = check_img("msnet_build_volume", l, r, out, Hb, Wb, ndisp, p.nccw)) return e;
+    if (int e = check_img("msnet_build_volume", l, r, out, Hb, Wb, ndisp, p.sadw)) return e;
+    if (int e = check_img("msnet_build_volume", l, r, out, Hb, Wb, ndisp, p.sobelw)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t vol = (size_t)ndisp * Hb * Wb, img = (size_t)Hb * Wb;
+    float* w = (float*)workspace;
+    float* raw_census = w; float* raw_ncc = w + vol; float* raw_sob = w + 2 * vol; float* raw_sad = w + 3 * vol;
+    float* sobl = w + 4 * vol; float* sobr = sobl + img;
+    float* integ = sobr + img;
+    uint32_t* bits = (uint32_t*)(integ + (size_t)ndisp * (Hb + 1) * (Wb + 1));
+
+    if (int e = census_impl(l, r, raw_census, bits, Hb, Wb, ndisp, p.censw, true, s)) return e;
+    if (int e = msnet_ncc(l, r, raw_ncc, Hb, Wb, ndisp, p.nccw, stream)) return e;
+    if (int e = msnet_zsad(l, r, raw_sad, Hb, Wb, ndisp, p.sadw, stream)) return e;
+    if (int e = msnet_sobel(l, sobl, Hb, Wb, stream)) return e;
+    if (int e = msnet_sobel(r, sobr, Hb, Wb, stream)) return e;
+    if (int e = sadsob_impl(sobl, sobr, raw_sob, integ, Hb, Wb, ndisp, p.sobelw, s)) return e;
+
+    AssembleArgs a;
+    a.raw[0] = raw_census; a.raw[1] = raw_ncc; a.raw[2] = raw_sob; a.raw[3] = raw_sad;
+    a.sigma[0] = p.cens_sigma; a.sigma[1] = p.ncc_sigma; a.sigma[2] = p.sad_sigma; a.sigma[3] = p.sad_sigma;
+    a.out = out; a.Hb = Hb; a.Wb = Wb; a.nd = ndisp; a.bh = p.border_h; a.bw = p.border_w; a.Hc = Hc; a.Wc = Wc;
+    LaunchScope ls("volume_assemble", s, 0, 4.0 * (8.0 * ndisp * Hc * Wc + 4.0 * vol));
+    hipLaunchKernelGGL(assemble_kernel, dim3(cdiv(Wc, 256), Hc, 4), dim3(256), 0, s, a);
+    return check_launch("msnet_build_volume");
+}

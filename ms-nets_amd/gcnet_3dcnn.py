@@ -1,0 +1,138 @@
+"""MS-GCNet cost-volume aggregator, drop-in for the reference class of the same name
+(/root/reference/src/models/gcnet_3dcnn.py:57-141) with the forward pass on hand-written HIP kernels.
+
+Contract kept from the reference:
+  * constructor signature and defaults (gcnet_3dcnn.py:58-65);
+  * parameter / buffer names, so reference checkpoints load unchanged:
+      conv3dbn_{1,2}.{0.weight,1.*}, block_3d_{1..4}.convbn_3d_{1..3}.{0,1}.*, deconvbn{1..4}.{0,1}.*,
+      deconv5.{weight,bias};
+  * forward(cv[N,C,D',H',W'] fp32 on the GPU) -> disp[N,H,W]; AssertionError when the regressed depth
+    differs from maxdisp (gcnet_3dcnn.py:135).
+Not kept: training-mode BatchNorm / autograd (the path is forward-only) and the CPU code path -- there is
+no fallback: without libmsnet_hip.so or a GPU tensor the forward raises.
+"""
+import torch
+import torch.nn as nn
+
+from . import hipops
+from .net_init import net_init
+
+
+def _convbn(cin, cout, stride):
+    return nn.Sequential(nn.Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False), nn.BatchNorm3d(cout))
+
+
+def _deconvbn(cin, cout):
+    return nn.Sequential(nn.ConvTranspose3d(cin, cout, 3, stride=2, padding=1, output_padding=1, bias=False),
+                         nn.BatchNorm3d(cout))
+
+
+class Conv3DBlock(nn.Module):
+    """Parameter container for one encoder level (three conv+BN+ReLU, first with the level's stride);
+    gcnet_3dcnn.py:30-44.  The arithmetic is issued by GCNet_CostVolumeAggre.forward."""
+
+    def __init__(self, in_planes, planes, stride=1, kernel_size=3):
+        super().__init__()
+        if kernel_size != 3:
+            raise ValueError("only kernel_size=3 is built")
+        self.convbn_3d_1 = _convbn(in_planes, planes, stride)
+        self.convbn_3d_2 = _convbn(planes, planes, 1)
+        self.convbn_3d_3 = _convbn(planes, planes, 1)
+        self.stride = stride
+
+
+class GCNet_CostVolumeAggre(nn.Module):
+    def __init__(self, maxdisp=192, cbmv_in_planes=8, kernel_size=3, is_quarter_input_size=False):
+        super().__init__()
+        if kernel_size != 3:
+            raise ValueError("only kernel_size=3 is built")
+        self.maxdisp = maxdisp
+        self.F = 32
+        self.kernel_size = kernel_size
+        self.is_quarter_input_size = bool(is_quarter_input_size)
+        F = self.F
+        self.conv3dbn_1 = _convbn(cbmv_in_planes, F, 1)
+        self.conv3dbn_2 = _convbn(F, F, 1)
+        self.block_3d_1 = Conv3DBlock(F, 2 * F, stride=2)
+        self.block_3d_2 = Conv3DBlock(2 * F, 2 * F, stride=2)
+        self.block_3d_3 = Conv3DBlock(2 * F, 2 * F, stride=2)
+        self.block_3d_4 = Conv3DBlock(2 * F, 4 * F, stride=2)
+        self.deconvbn1 = _deconvbn(4 * F, 2 * F)
+        self.deconvbn2 = _deconvbn(2 * F, 2 * F)
+        self.deconvbn3 = _deconvbn(2 * F, 2 * F)
+        self.deconvbn4 = _deconvbn(2 * F, F)
+        if self.is_quarter_input_size:   # gcnet_3dcnn.py:88-90
+            self.deconv5 = nn.ConvTranspose3d(F, 1, 3, stride=4, padding=1, output_padding=3)
+        else:
+            self.deconv5 = nn.ConvTranspose3d(F, 1, 3, stride=2, padding=1, output_padding=1)
+        net_init(self)
+        self._plan = None
+        self._plan_key = None
+
+    # ---- device constants ------------------------------------------------------------------------
+    def _plans(self):
+        key = hipops.state_key(self)
+        if self._plan is None or key != self._plan_key:
+            P = hipops.ConvBNPlan
+            plan = {"conv3dbn_1": P(*self.conv3dbn_1), "conv3dbn_2": P(*self.conv3dbn_2)}
+            for b in ("block_3d_1", "block_3d_2", "block_3d_3", "block_3d_4"):
+                blk = getattr(self, b)
+                for c in ("convbn_3d_1", "convbn_3d_2", "convbn_3d_3"):
+                    plan[b + "." + c] = P(*getattr(blk, c))
+            for dname in ("deconvbn1", "deconvbn2", "deconvbn3", "deconvbn4"):
+                plan[dname] = P(*getattr(self, dname), transposed=True)
+            plan["deconv5.w"] = self.deconv5.weight.detach().float().contiguous()
+            plan["deconv5.b"] = float(self.deconv5.bias.detach().float().item())
+            self._plan, self._plan_key = plan, key
+        return self._plan
+
+    # ---- forward -----------------------------------------------------------------------------------
+    def forward(self, cv, taps=None):
+        """cv [N,C,D',H',W'] -> disparity [N,H,W].  `taps`: optional dict that receives every layer output
+        converted back to NCDHW under the reference's names (parity tests only)."""
+        if self.training:
+            raise RuntimeError("GCNet_CostVolumeAggre (HIP) is forward/inference only: call .eval() first")
+        cv = hipops.require_gpu_f32(cv, "cv")
+        if cv.dim() != 5:
+            raise ValueError("cv must be [N,C,D,H,W]")
+        pl = self._plans()
+
+        def tap(name, t):
+            if taps is not None:
+                taps[name] = hipops.ndhwc_to_ncdhw(t)
+            return t
+
+        def conv(x, name, stride=1, residual=None):
+            p = pl[name]
+            return hipops.conv3d_k3(x, p.wpk, p.scale, p.shift, p.co, stride=stride, relu=True, residual=residual)
+
+        def block(x, name, stride):
+            x = conv(x, name + ".convbn_3d_1", stride)
+            x = conv(x, name + ".convbn_3d_2")
+            return tap(name, conv(x, name + ".convbn_3d_3"))
+
+        def deconv(x, name, skip):
+            p = pl[name]
+            return tap(name, hipops.deconv3d_k3s2(x, p.wpk, p.scale, p.shift, p.co, relu=True, residual=skip))
+
+        with torch.no_grad():
+            x = hipops.ncdhw_to_ndhwc(cv)
+            x = tap("conv3dbn_1", conv(x, "conv3dbn_1"))
+            res_l20 = x = tap("conv3dbn_2", conv(x, "conv3dbn_2"))
+            res_l23 = x = block(x, "block_3d_1", 2)
+            res_l26 = x = block(x, "block_3d_2", 2)
+            res_l29 = x = block(x, "block_3d_3", 2)
+            x = block(x, "block_3d_4", 2)
+            x = deconv(x, "deconvbn1", res_l29)
+            x = deconv(x, "deconvbn2", res_l26)
+            x = deconv(x, "deconvbn3", res_l23)
+            x = deconv(x, "deconvbn4", res_l20)
+            s = 4 if self.is_quarter_input_size else 2
+            depth = s * x.shape[1]
+            assert depth == self.maxdisp, "%d != %d" % (depth, self.maxdisp)   # gcnet_3dcnn.py:135
+            if s == 2 and taps is None:
+                return hipops.deconv5_softargmin(x, pl["deconv5.w"], pl["deconv5.b"])
+            logits = hipops.deconv3d_cout1(x, pl["deconv5.w"], pl["deconv5.b"], stride=s)
+            if taps is not None:
+                taps["deconv5"] = logits.unsqueeze(1)
+            return hipops.softargmin(logits)

@@ -1,0 +1,145 @@
+"""PSMNet-style stacked-hourglass cost-volume aggregator, drop-in for
+/root/reference/src/models/psmnet_3dcnn.py:47-179 with the forward pass on hand-written HIP kernels.
+
+Contract kept from the reference (module as released, SURVEY.md defects D2/D3):
+  * PSMNet_CostVolumeAggre(maxdisp); input cost [N,64,D/4,H/4,W/4] fp32 on the GPU; eval forward -> pred3 [N,H,W];
+  * parameter / buffer names: dres0.{0,2}.{0,1}.*, dres1.{0,2}.{0,1}.*, dres{2,3,4}.conv{1,3,4}.0.{0,1}.*,
+    dres{2,3,4}.conv{2,5,6}.{0,1}.*, classif{1,2,3}.{0.0,0.1,2}.*  (reference checkpoints load unchanged).
+The reference reads an undefined global ``left`` for the output size (psmnet_3dcnn.py:153,155,167); its only
+possible meaning is the full-resolution image, so forward takes ``out_hw`` and defaults to 4x the input H,W.
+Training-mode BatchNorm / autograd are not provided (forward-only path); ``forward_all_heads`` returns the
+three predictions the reference returns in training mode, computed with eval-mode statistics.
+"""
+import torch
+import torch.nn as nn
+
+from . import hipops
+from .net_init import net_init
+
+
+def _convbn(cin, cout, stride):
+    return nn.Sequential(nn.Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False), nn.BatchNorm3d(cout))
+
+
+def _deconvbn(cin, cout):
+    return nn.Sequential(nn.ConvTranspose3d(cin, cout, 3, padding=1, output_padding=1, stride=2, bias=False),
+                         nn.BatchNorm3d(cout))
+
+
+class hourglass(nn.Module):
+    """Parameter container of one hourglass (psmnet_3dcnn.py:47-67); arithmetic in PSMNet_CostVolumeAggre."""
+
+    def __init__(self, inplanes):
+        super().__init__()
+        c = inplanes
+        self.conv1 = nn.Sequential(_convbn(c, 2 * c, 2), nn.ReLU(inplace=True))
+        self.conv2 = _convbn(2 * c, 2 * c, 1)
+        self.conv3 = nn.Sequential(_convbn(2 * c, 2 * c, 2), nn.ReLU(inplace=True))
+        self.conv4 = nn.Sequential(_convbn(2 * c, 2 * c, 1), nn.ReLU(inplace=True))
+        self.conv5 = _deconvbn(2 * c, 2 * c)
+        self.conv6 = _deconvbn(2 * c, c)
+
+
+def _classif():
+    return nn.Sequential(_convbn(32, 32, 1), nn.ReLU(inplace=True),
+                         nn.Conv3d(32, 1, kernel_size=3, padding=1, stride=1, bias=False))
+
+
+class PSMNet_CostVolumeAggre(nn.Module):
+    def __init__(self, maxdisp):
+        super().__init__()
+        self.maxdisp = maxdisp
+        self.dres0 = nn.Sequential(_convbn(64, 32, 1), nn.ReLU(inplace=True), _convbn(32, 32, 1), nn.ReLU(inplace=True))
+        self.dres1 = nn.Sequential(_convbn(32, 32, 1), nn.ReLU(inplace=True), _convbn(32, 32, 1))
+        self.dres2 = hourglass(32)
+        self.dres3 = hourglass(32)
+        self.dres4 = hourglass(32)
+        self.classif1 = _classif()
+        self.classif2 = _classif()
+        self.classif3 = _classif()
+        net_init(self)
+        self._plan = None
+        self._plan_key = None
+
+    def _plans(self):
+        key = hipops.state_key(self)
+        if self._plan is None or key != self._plan_key:
+            P = hipops.ConvBNPlan
+            pl = {"dres0.0": P(*self.dres0[0]), "dres0.2": P(*self.dres0[2]),
+                  "dres1.0": P(*self.dres1[0]), "dres1.2": P(*self.dres1[2])}
+            for h in ("dres2", "dres3", "dres4"):
+                hg = getattr(self, h)
+                pl[h + ".conv1"] = P(*hg.conv1[0])
+                pl[h + ".conv2"] = P(*hg.conv2)
+                pl[h + ".conv3"] = P(*hg.conv3[0])
+                pl[h + ".conv4"] = P(*hg.conv4[0])
+                pl[h + ".conv5"] = P(*hg.conv5, transposed=True)
+                pl[h + ".conv6"] = P(*hg.conv6, transposed=True)
+            for c in ("classif1", "classif2", "classif3"):
+                seq = getattr(self, c)
+                pl[c + ".0"] = P(*seq[0])
+                pl[c + ".2"] = seq[2].weight.detach().float().contiguous()
+            self._plan, self._plan_key = pl, key
+        return self._plan
+
+    def _trunk(self, cost, taps):
+        pl = self._plans()
+
+        def tap(name, t):
+            if taps is not None:
+                taps[name] = hipops.ndhwc_to_ncdhw(t) if t.dim() == 5 else t.unsqueeze(1)
+            return t
+
+        def conv(x, name, stride=1, relu=True, residual=None):
+            p = pl[name]
+            return hipops.conv3d_k3(x, p.wpk, p.scale, p.shift, p.co, stride=stride, relu=relu, residual=residual)
+
+        def deconv(x, name, relu, residual):
+            p = pl[name]
+            return hipops.deconv3d_k3s2(x, p.wpk, p.scale, p.shift, p.co, relu=relu, residual=residual)
+
+        def hour(x, name, presqu, postsqu, skip):
+            # psmnet_3dcnn.py:69-89; `skip` (= cost0) is the "+ cost0" the caller adds to the hourglass output
+            out = conv(x, name + ".conv1", stride=2)
+            pre = conv(out, name + ".conv2", relu=True, residual=postsqu)
+            out = conv(pre, name + ".conv3", stride=2)
+            out = conv(out, name + ".conv4")
+            post = deconv(out, name + ".conv5", True, presqu if presqu is not None else pre)
+            out = deconv(post, name + ".conv6", False, skip)
+            return out, pre, post
+
+        x = hipops.ncdhw_to_ndhwc(cost)
+        c0 = conv(conv(x, "dres0.0"), "dres0.2")
+        cost0 = tap("cost0", conv(conv(c0, "dres1.0"), "dres1.2", relu=False, residual=c0))
+        out1, pre1, post1 = hour(cost0, "dres2", None, None, cost0)
+        tap("out1", out1)
+        out2, _, post2 = hour(out1, "dres3", pre1, post1, cost0)
+        tap("out2", out2)
+        out3, _, _ = hour(out2, "dres4", pre1, post2, cost0)
+        tap("out3", out3)
+        cost1 = hipops.conv3d_k3_cout1(conv(out1, "classif1.0"), pl["classif1.2"])
+        cost2 = hipops.conv3d_k3_cout1(conv(out2, "classif2.0"), pl["classif2.2"], add=cost1)
+        cost3 = tap("cost3", hipops.conv3d_k3_cout1(conv(out3, "classif3.0"), pl["classif3.2"], add=cost2))
+        return cost1, cost2, cost3
+
+    def _check(self, cost):
+        if self.training:
+            raise RuntimeError("PSMNet_CostVolumeAggre (HIP) is forward/inference only: call .eval() first")
+        cost = hipops.require_gpu_f32(cost, "cost")
+        if cost.dim() != 5 or cost.shape[1] != 64:
+            raise ValueError("cost must be [N,64,D/4,H/4,W/4] (got %s)" % (tuple(cost.shape),))
+        return cost
+
+    def forward(self, cost, out_hw=None, taps=None):
+        cost = self._check(cost)
+        H, W = out_hw if out_hw is not None else (4 * cost.shape[3], 4 * cost.shape[4])
+        with torch.no_grad():
+            _, _, cost3 = self._trunk(cost, taps)
+            return hipops.trilinear_softargmin(cost3, (self.maxdisp, H, W))
+
+    def forward_all_heads(self, cost, out_hw=None):
+        """(pred1, pred2, pred3) as the reference's training-mode return (psmnet_3dcnn.py:149-177)."""
+        cost = self._check(cost)
+        H, W = out_hw if out_hw is not None else (4 * cost.shape[3], 4 * cost.shape[4])
+        with torch.no_grad():
+            return tuple(hipops.trilinear_softargmin(c, (self.maxdisp, H, W)) for c in self._trunk(cost, None))

@@ -1,0 +1,244 @@
+/*
+ * ORACLE (test infrastructure, not product code): plain-C CPU restatement of the matching-space
+ * matchers and likelihood features of ccj5351/MS-Nets.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this; the shipped path is ms-nets_amd/csrc/volume.hip.
+ *
+ * PARITY UNPINNED for this file: the reference implementation (src/cpp/matchers/matchers.cpp and
+ * src/cpp/featextract/featextract.cpp) is a Boost.Python extension; Boost.Python is not in this image and
+ * building it against stand-in headers is not allowed, so the reference C++ was never executed next to
+ * this restatement in the repo's own test-suite, and the reference ships no golden vectors or tests for it.
+ * Each function follows the reference line by line (cited below), including loop bounds (i < H-wsize,
+ * not <=), the RAND_MAX fill of unwritten entries, float32 accumulation ORDER and the double-precision
+ * NCC arithmetic.  (The survey's out-of-tree probe reported bit-exact agreement of an equivalent NumPy
+ * restatement with the compiled reference on a 37x53, D=12 pair; that probe is not reproducible here.)
+ *
+ * Build: see oracle/Makefile (-O2 -ffp-contract=off: no FMA contraction, no re-association).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define SENTINEL ((float)RAND_MAX) /* std::fill_n(float*, n, RAND_MAX): 2147483647 -> 2^31 as float */
+
+static void fill(float* p, size_t n, float v) {
+    for (size_t i = 0; i < n; ++i) p[i] = v;
+}
+
+/* census(left,right,ndisp,wsize): matchers.cpp:232-353.  out[H][W][ndisp].
+ * The reference compares int16 lanes center < pixel (:290-297), pads wsize^2 lanes to a multiple of 8 with
+ * zeros in both images (calloc'd vecl/vecr, :279-280; 0 > center is false on both sides, so pad lanes are
+ * always equal) and returns vecsize - #equal lanes (:323-337) = number of differing census bits. */
+void oracle_census(const uint8_t* l, const uint8_t* r, float* out, int H, int W, int nd, int ws) {
+    const int wc = ws / 2, nb = ws * ws;
+    fill(out, (size_t)H * W * nd, SENTINEL);
+    uint8_t* cl = (uint8_t*)calloc((size_t)H * W * nb, 1);
+    uint8_t* cr = (uint8_t*)calloc((size_t)H * W * nb, 1);
+#pragma omp parallel for
+    for (int i = 0; i < H - ws; ++i)
+        for (int j = 0; j < W - ws; ++j) {
+            const int16_t centl = l[(i + wc) * W + j + wc], centr = r[(i + wc) * W + j + wc];
+            uint8_t* bl = cl + ((size_t)(i + wc) * W + j + wc) * nb;
+            uint8_t* br = cr + ((size_t)(i + wc) * W + j + wc) * nb;
+            for (int wh = 0; wh < ws; ++wh)
+                for (int ww = 0; ww < ws; ++ww) {
+                    bl[wh * ws + ww] = centl < (int16_t)l[(i + wh) * W + j + ww];
+                    br[wh * ws + ww] = centr < (int16_t)r[(i + wh) * W + j + ww];
+                }
+        }
+#pragma omp parallel for
+    for (int i = 0; i < H - ws; ++i)
+        for (int j = 0; j < W - ws; ++j) {
+            const int end = nd < j + 1 ? nd : j + 1;                       /* :318 */
+            const uint8_t* bl = cl + ((size_t)(i + wc) * W + j + wc) * nb;
+            for (int d = 0; d < end; ++d) {
+                const uint8_t* br = cr + ((size_t)(i + wc) * W + j - d + wc) * nb;
+                int diff = 0;
+                for (int b = 0; b < nb; ++b) diff += bl[b] != br[b];
+                out[((size_t)(i + wc) * W + j + wc) * nd + d] = (float)diff;
+            }
+        }
+    free(cl);
+    free(cr);
+}
+
+/* nccNister(left,right,ndisp,wsize): matchers.cpp:47-228.  out[ndisp][H][W].
+ * u32 / u64 integral images of I and I^2 (:71-122), per-disparity double integral of L*R_shift (:155-184),
+ * C = 1/sqrt(n*B - A*A) in double (:146-147), cost = (float)( -(n*lD - Al*Ar) * Cl * Cr ) or 1 when either
+ * C is not finite (:196-205). */
+void oracle_ncc(const uint8_t* l, const uint8_t* r, float* out, int H, int W, int nd, int ws) {
+    const int wc = ws / 2, sq = ws * ws, IR = H + 1, IC = W + 1;
+    fill(out, (size_t)nd * H * W, SENTINEL);
+    unsigned int* li = (unsigned int*)calloc((size_t)IR * IC, sizeof(unsigned int));
+    unsigned int* ri = (unsigned int*)calloc((size_t)IR * IC, sizeof(unsigned int));
+    unsigned long long* lq = (unsigned long long*)calloc((size_t)IR * IC, sizeof(unsigned long long));
+    unsigned long long* rq = (unsigned long long*)calloc((size_t)IR * IC, sizeof(unsigned long long));
+    for (int i = 0; i < H; ++i)
+        for (int j = 0; j < W; ++j) {
+            const size_t k = (size_t)(i + 1) * IC + j + 1;
+            li[k] = l[i * W + j]; lq[k] = (unsigned long long)(l[i * W + j] * l[i * W + j]);
+            ri[k] = r[i * W + j]; rq[k] = (unsigned long long)(r[i * W + j] * r[i * W + j]);
+        }
+    for (int i = 1; i < IR; ++i)
+        for (int j = 0; j < IC; ++j) {
+            li[i * IC + j] += li[(i - 1) * IC + j]; ri[i * IC + j] += ri[(i - 1) * IC + j];
+            lq[i * IC + j] += lq[(i - 1) * IC + j]; rq[i * IC + j] += rq[(i - 1) * IC + j];
+        }
+    for (int i = 0; i < IR; ++i)
+        for (int j = 1; j < IC; ++j) {
+            li[i * IC + j] += li[i * IC + j - 1]; ri[i * IC + j] += ri[i * IC + j - 1];
+            lq[i * IC + j] += lq[i * IC + j - 1]; rq[i * IC + j] += rq[i * IC + j - 1];
+        }
+    unsigned long long* Al = (unsigned long long*)calloc((size_t)H * W, sizeof(unsigned long long));
+    unsigned long long* Ar = (unsigned long long*)calloc((size_t)H * W, sizeof(unsigned long long));
+    double* Cl = (double*)calloc((size_t)H * W, sizeof(double));
+    double* Cr = (double*)calloc((size_t)H * W, sizeof(double));
+    for (int i = 0; i < H - ws; ++i)
+        for (int j = 0; j < W - ws; ++j) {
+            const size_t c = (size_t)(i + wc) * W + j + wc;
+            const size_t t = (size_t)i * IC, b = (size_t)(i + ws) * IC;
+            Al[c] = li[b + j + ws] + li[t + j] - li[b + j] - li[t + j + ws];
+            Ar[c] = ri[b + j + ws] + ri[t + j] - ri[b + j] - ri[t + j + ws];
+            const unsigned long long Bl = lq[b + j + ws] + lq[t + j] - lq[b + j] - lq[t + j + ws];
+            const unsigned long long Br = rq[b + j + ws] + rq[t + j] - rq[b + j] - rq[t + j + ws];
+            Cl[c] = 1 / (sqrt(sq * Bl - (double)(Al[c]) * (Al[c])));
+            Cr[c] = 1 / (sqrt(sq * Br - (double)(Ar[c]) * (Ar[c])));
+        }
+#pragma omp parallel
+    {
+        double* ds = (double*)calloc((size_t)IR * IC, sizeof(double));
+#pragma omp for
+        for (int d = 0; d < nd; ++d) {
+            memset(ds, 0, (size_t)IR * IC * sizeof(double));
+            for (int i = 0; i < H; ++i)
+                for (int j = d; j < W; ++j) ds[(size_t)(i + 1) * IC + j + 1] = l[i * W + j] * r[i * W + j - d];
+            for (int i = 1; i < IR; ++i)
+                for (int j = 0; j < IC; ++j) ds[(size_t)i * IC + j] += ds[(size_t)(i - 1) * IC + j];
+            for (int i = 0; i < IR; ++i)
+                for (int j = 1; j < IC; ++j) ds[(size_t)i * IC + j] += ds[(size_t)i * IC + j - 1];
+            for (int i = 0; i < H - ws; ++i) {
+                const size_t row = (size_t)(i + wc) * W, t = (size_t)i * IC, b = (size_t)(i + ws) * IC;
+                for (int j = d; j < W - ws; ++j) {
+                    const size_t col = j + wc;
+                    const double lD = ds[b + j + ws] + ds[t + j] - ds[b + j] - ds[t + j + ws];
+                    float v;
+                    if (isfinite(Cl[row + col]) && isfinite(Cr[row + (j - d + wc)])) {
+                        const double tmp = -(double)(sq * lD - Al[row + col] * Ar[row + (j - d + wc)]) * Cl[row + col] *
+                                           Cr[row + (j - d + wc)];
+                        v = (float)tmp;
+                    } else {
+                        v = (float)1;
+                    }
+                    out[(size_t)d * H * W + row + col] = v;
+                }
+            }
+        }
+        free(ds);
+    }
+    free(li); free(ri); free(lq); free(rq); free(Al); free(Ar); free(Cl); free(Cr);
+}
+
+/* zsad(left,right,ndisp,wsize): matchers.cpp:442-512.  out[ndisp][H][W].
+ * Window means accumulate in float32 in (wh,ww) order then divide by wsize^2 (:472-485); the cost is the
+ * float32 running sum of fabs(L - meanL - R_shift + meanR_shift), evaluated left to right (:492-509). */
+void oracle_zsad(const uint8_t* l, const uint8_t* r, float* out, int H, int W, int nd, int ws) {
+    const int wc = ws / 2, sq = ws * ws;
+    fill(out, (size_t)nd * H * W, SENTINEL);
+    float* ml = (float*)calloc((size_t)H * W, sizeof(float));
+    float* mr = (float*)calloc((size_t)H * W, sizeof(float));
+    for (int i = 0; i < H - ws; ++i)
+        for (int j = 0; j < W - ws; ++j) {
+            const size_t c = (size_t)(i + wc) * W + j + wc;
+            for (int wh = 0; wh < ws; ++wh)
+                for (int ww = 0; ww < ws; ++ww) {
+                    ml[c] += l[(i + wh) * W + j + ww];
+                    mr[c] += r[(i + wh) * W + j + ww];
+                }
+            ml[c] /= sq;
+            mr[c] /= sq;
+        }
+#pragma omp parallel for
+    for (int d = 0; d < nd; ++d)
+        for (int i = 0; i < H - ws; ++i) {
+            const size_t row = (size_t)(i + wc) * W;
+            for (int j = d; j < W - ws; ++j) {
+                float acc = 0;
+                for (int wh = 0; wh < ws; ++wh)
+                    for (int ww = 0; ww < ws; ++ww)
+                        acc += fabsf(l[(i + wh) * W + j + ww] - ml[row + j + wc] - r[(i + wh) * W + (j - d) + ww] +
+                                     mr[row + (j - d) + wc]);
+                out[(size_t)d * H * W + row + j + wc] = acc;
+            }
+        }
+    free(ml);
+    free(mr);
+}
+
+/* sobel(img): matchers.cpp:515-554.  Horizontal-gradient 3x3 Sobel in int, placed at (i+1,j+1) for
+ * i < H-3, j < W-3, zero elsewhere. */
+void oracle_sobel(const uint8_t* img, float* out, int H, int W) {
+    memset(out, 0, (size_t)H * W * sizeof(float));
+    for (int i = 0; i < H - 3; ++i)
+        for (int j = 0; j < W - 3; ++j) {
+            const uint8_t* p = img + i * W + j;
+            const float v = -1 * p[0] + 0 * p[1] + 1 * p[2] + -2 * p[W] + 0 * p[W + 1] + 2 * p[W + 2] + -1 * p[2 * W] +
+                            0 * p[2 * W + 1] + 1 * p[2 * W + 2];
+            out[(i + 1) * W + j + 1] = v;
+        }
+}
+
+/* sadsob(sobl,sobr,ndisp,wsize): matchers.cpp:356-438.  out[ndisp][H][W].
+ * Per disparity: float32 slice of |SL - SR_shift| (:388-394), sequential vertical pass over columns
+ * j >= d (:396-403), sequential horizontal pass from j = d+1 (:406-411), then the 4-corner box in the order
+ * S[b][r] - S[b][l] - S[t][r] + S[t][l] (:421-423). */
+void oracle_sadsob(const float* sl, const float* sr, float* out, int H, int W, int nd, int ws) {
+    const int wc = ws / 2, IR = H + 1, IC = W + 1;
+    fill(out, (size_t)nd * H * W, SENTINEL);
+#pragma omp parallel
+    {
+        float* s = (float*)malloc((size_t)IR * IC * sizeof(float));
+#pragma omp for
+        for (int d = 0; d < nd; ++d) {
+            for (size_t k = 0; k < (size_t)IR * IC; ++k) s[k] = 0;
+            for (int i = 0; i < H; ++i)
+                for (int j = d; j < W; ++j) s[(size_t)(i + 1) * IC + j + 1] = fabsf(sl[i * W + j] - sr[i * W + (j - d)]);
+            for (int i = 1; i < IR; ++i)
+                for (int j = d; j < IC; ++j) s[(size_t)i * IC + j] += s[(size_t)(i - 1) * IC + j];
+            for (int i = 0; i < IR; ++i)
+                for (int j = d + 1; j < IC; ++j) s[(size_t)i * IC + j] += s[(size_t)i * IC + j - 1];
+            for (int i = 0; i < H - ws; ++i) {
+                const size_t t = (size_t)i * IC, b = (size_t)(i + ws) * IC;
+                for (int j = d; j < W - ws; ++j)
+                    out[(size_t)d * H * W + (size_t)(i + wc) * W + j + wc] = s[b + (j + ws)] - s[b + j] - s[t + (j + ws)] + s[t + j];
+            }
+        }
+        free(s);
+    }
+}
+
+/* swap_axes(cost): featextract.cpp:49-76.  [D][H][W] -> [H][W][D]. */
+void oracle_swap_axes(const float* in, float* out, int D, int H, int W) {
+    const size_t S = (size_t)H * W;
+    for (size_t i = 0; i < S; ++i)
+        for (int j = 0; j < D; ++j) out[i * D + j] = in[(size_t)j * S + i];
+}
+
+/* extract_likelihood(vol,sigma) = extract_aml_testing: featextract.cpp:415-462.  vol,out [P][D].
+ * All arithmetic in float32 (std::exp(float) -> expf), denominator accumulated sequentially. */
+void oracle_extract_likelihood(const float* vol, float* out, long P, int D, float sigma) {
+#pragma omp parallel for
+    for (long i = 0; i < P; ++i) {
+        const float* v = vol + (size_t)i * D;
+        float min_cost = SENTINEL, denom = 0, num = 0;
+        for (int k = 0; k < D; ++k)
+            if (v[k] < min_cost) min_cost = v[k];
+        for (int k = 0; k < D; ++k) {
+            num = v[k] - min_cost;
+            denom += expf(-(num * num) / sigma);
+        }
+        for (int j = 0; j < D; ++j) {
+            const float t = v[j] - min_cost;
+            out[(size_t)i * D + j] = (min_cost == SENTINEL) ? 0.0f : expf(-((t * t) / sigma)) / denom;
+        }
+    }
+}

@@ -1,0 +1,248 @@
+"""GPU parity of the aggregator kernels, called through the C ABI (ctypes), against
+ (a) plain torch fp32 CPU ops for single layers,
+ (b) the golden vectors the reference produced (tests/golden/aggregators_*.npz),
+ (c) the oracle restatement on every intermediate activation.
+Tolerance on disparity: 1e-3 abs (BASELINE.json north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import recipes
+from oracle import aggregators as oracle
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+DISP_TOL = 1e-3
+
+
+def _cl(x):      # NCDHW cpu -> NDHWC gpu
+    return x.permute(0, 2, 3, 4, 1).contiguous().cuda()
+
+
+def _nc(y):      # NDHWC gpu -> NCDHW cpu
+    return y.cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / max(1e-6, float(b.abs().max())))
+
+
+def test_layout_roundtrip(gpu):
+    from msnets_amd import hipops
+    for shape in [(1, 8, 5, 7, 33), (2, 32, 3, 4, 70), (1, 64, 2, 9, 31), (1, 1, 4, 4, 4)]:
+        x = torch.rand(shape)
+        y = hipops.ncdhw_to_ndhwc(x.cuda())
+        assert torch.equal(y.cpu(), x.permute(0, 2, 3, 4, 1).contiguous()), shape
+        assert torch.equal(hipops.ndhwc_to_ncdhw(y).cpu(), x), shape
+
+
+CONV_CASES = [
+    # Ci, Co, stride, (N,D,H,W), relu, residual
+    (8, 32, 1, (1, 6, 10, 37), True, False),
+    (8, 32, 1, (2, 4, 8, 32), False, True),
+    (32, 32, 1, (1, 4, 9, 40), True, False),
+    (32, 32, 1, (1, 3, 8, 32), True, True),
+    (32, 64, 1, (1, 5, 6, 19), True, False),
+    (64, 64, 1, (1, 4, 10, 24), True, True),
+    (64, 32, 1, (1, 4, 8, 48), True, False),
+    (128, 128, 1, (1, 3, 5, 9), True, False),
+    (16, 32, 1, (1, 3, 5, 20), False, False),
+    (32, 64, 2, (1, 8, 12, 34), True, False),
+    (64, 64, 2, (1, 6, 9, 33), True, False),
+    (64, 128, 2, (1, 4, 6, 10), True, False),
+    (32, 32, 2, (2, 5, 7, 21), False, False),
+]
+
+
+@pytest.mark.parametrize("ci,co,stride,dims,relu,use_res", CONV_CASES)
+def test_conv3d_layer(gpu, ci, co, stride, dims, relu, use_res):
+    from msnets_amd import hipops
+    g = torch.Generator().manual_seed(ci * 1000 + co + stride)
+    n, d, h, w = dims
+    x = torch.randn((n, ci, d, h, w), generator=g)
+    wt = torch.randn((co, ci, 3, 3, 3), generator=g) * (2.0 / (27 * ci)) ** 0.5
+    scale = torch.rand(co, generator=g) + 0.5
+    shift = torch.randn(co, generator=g) * 0.1
+    ref = F.conv3d(x, wt, None, stride=stride, padding=1) * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    wpk = hipops.pack_conv_weight(wt.cuda())
+    y = hipops.conv3d_k3(_cl(x), wpk, scale.cuda(), shift.cuda(), co, stride=stride, relu=relu,
+                         residual=_cl(res) if use_res else None)
+    assert tuple(_nc(y).shape) == tuple(ref.shape)
+    assert _rel(_nc(y), ref) < 2e-5
+
+
+DECONV_CASES = [
+    (128, 64, (1, 3, 5, 9), True, True),
+    (64, 64, (1, 4, 6, 20), True, True),
+    (64, 64, (1, 3, 5, 33), True, False),
+    (64, 32, (1, 4, 9, 17), True, True),
+    (64, 32, (2, 3, 4, 32), False, True),
+    (32, 32, (1, 3, 6, 18), False, False),
+    (32, 64, (1, 2, 5, 35), True, False),
+]
+
+
+@pytest.mark.parametrize("ci,co,dims,relu,use_res", DECONV_CASES)
+def test_deconv3d_layer(gpu, ci, co, dims, relu, use_res):
+    from msnets_amd import hipops
+    g = torch.Generator().manual_seed(ci * 77 + co)
+    n, d, h, w = dims
+    x = torch.randn((n, ci, d, h, w), generator=g)
+    wt = torch.randn((ci, co, 3, 3, 3), generator=g) * (2.0 / (27 * ci)) ** 0.5
+    scale = torch.rand(co, generator=g) + 0.5
+    shift = torch.randn(co, generator=g) * 0.1
+    ref = F.conv_transpose3d(x, wt, None, stride=2, padding=1, output_padding=1)
+    ref = ref * scale.view(1, -1, 1, 1, 1) + shift.view(1, -1, 1, 1, 1)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res
+    if relu:
+        ref = F.relu(ref)
+    wpk = hipops.pack_conv_weight(wt.cuda(), transposed=True)
+    y = hipops.deconv3d_k3s2(_cl(x), wpk, scale.cuda(), shift.cuda(), co, relu=relu, residual=_cl(res) if use_res else None)
+    assert tuple(_nc(y).shape) == tuple(ref.shape)
+    assert _rel(_nc(y), ref) < 2e-5
+
+
+@pytest.mark.parametrize("dims,use_add", [((1, 5, 9, 33), False), ((2, 4, 8, 40), True), ((1, 1, 3, 5), False)])
+def test_conv3d_cout1_head(gpu, dims, use_add):
+    from msnets_amd import hipops
+    g = torch.Generator().manual_seed(5)
+    n, d, h, w = dims
+    x = torch.randn((n, 32, d, h, w), generator=g)
+    wt = torch.randn((1, 32, 3, 3, 3), generator=g) * 0.05
+    ref = F.conv3d(x, wt, None, padding=1).squeeze(1)
+    add = torch.randn(ref.shape, generator=g) if use_add else None
+    if use_add:
+        ref = ref + add
+    y = hipops.conv3d_k3_cout1(_cl(x), wt.cuda(), add.cuda() if use_add else None)
+    assert _rel(y.cpu(), ref) < 2e-5
+
+
+@pytest.mark.parametrize("dims,stride", [((1, 4, 9, 35), 2), ((2, 3, 8, 32), 2), ((1, 3, 4, 6), 4)])
+def test_deconv5_logits_and_fused_tail(gpu, dims, stride):
+    from msnets_amd import hipops
+    g = torch.Generator().manual_seed(9)
+    n, d, h, w = dims
+    x = torch.randn((n, 32, d, h, w), generator=g)
+    wt = torch.randn((32, 1, 3, 3, 3), generator=g) * 0.2
+    bias = 0.37
+    ref = F.conv_transpose3d(x, wt, torch.tensor([bias]), stride=stride, padding=1, output_padding=stride - 1).squeeze(1)
+    logits = hipops.deconv3d_cout1(_cl(x), wt.cuda(), bias, stride=stride)
+    assert tuple(logits.shape) == tuple(ref.shape)
+    assert _rel(logits.cpu(), ref) < 2e-5
+    ref_disp = oracle.soft_argmin(ref)
+    assert float((hipops.softargmin(logits).cpu() - ref_disp).abs().max()) < 1e-4
+    if stride == 2:
+        fused = hipops.deconv5_softargmin(_cl(x), wt.cuda(), bias)
+        assert float((fused.cpu() - ref_disp).abs().max()) < 1e-4
+
+
+def test_softargmin_peaky_and_flat(gpu):
+    from msnets_amd import hipops
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn((2, 192, 5, 7), generator=g) * 30.0     # peaky
+    assert float((hipops.softargmin(logits.cuda()).cpu() - oracle.soft_argmin(logits)).abs().max()) < 1e-4
+    flat = torch.zeros((1, 64, 3, 3))
+    assert float((hipops.softargmin(flat.cuda()).cpu() - 31.5).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("in_dhw,out_dhw", [((8, 16, 16), (32, 64, 64)), ((8, 8, 24), (32, 32, 96)), ((5, 7, 9), (17, 30, 33)),
+                                            ((48, 17, 30), (192, 68, 120))])
+def test_trilinear_softargmin(gpu, in_dhw, out_dhw):
+    from msnets_amd import hipops
+    g = torch.Generator().manual_seed(11)
+    cost = torch.randn((2, 1) + in_dhw, generator=g) * 4
+    ref = oracle.soft_argmin(F.interpolate(cost, list(out_dhw), mode="trilinear", align_corners=True).squeeze(1))
+    got = hipops.trilinear_softargmin(cost.squeeze(1).cuda(), out_dhw)
+    assert float((got.cpu() - ref).abs().max()) < 2e-4
+
+
+def _our_classes():
+    from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre
+    from msnets_amd.psmnet_3dcnn import PSMNet_CostVolumeAggre
+    return GCNet_CostVolumeAggre, PSMNet_CostVolumeAggre
+
+
+@pytest.mark.parametrize("name", sorted(recipes.AGG_CASES))
+def test_golden_end_to_end(gpu, name):
+    """HIP module vs the reference's own output on the same seeded weights and input."""
+    case = recipes.AGG_CASES[name]
+    gold = np.load(os.path.join(GOLD, "aggregators_%s.npz" % name))
+    model = recipes.build_case(case, *_our_classes())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    assert recipes.state_sha256(sd) == str(gold["state_sha256"])
+    x = recipes.make_input(case["in_shape"], case["seed"])
+    model = model.cuda()
+    disp = model(x.cuda()).cpu()            # fused-tail path
+    err = float(np.abs(disp.numpy() - gold["disp"]).max())
+    print("%s: max|disp - reference| = %.3e" % (name, err))
+    assert err <= DISP_TOL
+    # every intermediate activation against the oracle (un-fused tail path, exercises msnet_softargmin too)
+    taps_hip, taps_or = {}, {}
+    disp2 = model(x.cuda(), taps=taps_hip).cpu()
+    assert float(np.abs(disp2.numpy() - gold["disp"]).max()) <= DISP_TOL
+    with torch.no_grad():
+        if case["model"] == "gcnet":
+            oracle.gcnet_forward(sd, x, case["maxdisp"], bool(case.get("quarter")), taps=taps_or)
+        else:
+            oracle.psmnet_forward(sd, x, case["maxdisp"], recipes.out_hw(case), taps=taps_or)
+    assert taps_hip, "no taps captured"
+    for t, v in taps_hip.items():
+        assert _rel(v.cpu(), taps_or[t]) < 1e-4, t
+    for key in gold.files:                  # and against the reference's own sampled activations
+        if key.startswith("tap_") and key[4:] in taps_hip:
+            s, _ = recipes.sample(taps_hip[key[4:]].cpu())
+            assert np.abs(s - gold[key]).max() <= 1e-4 * max(1.0, float(np.abs(gold[key]).max())), key
+
+
+def test_psmnet_all_heads(gpu):
+    case = recipes.AGG_CASES["psmnet_small"]
+    model = recipes.build_case(case, *_our_classes())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = recipes.make_input(case["in_shape"], case["seed"])
+    got = model.cuda().forward_all_heads(x.cuda())
+    with torch.no_grad():
+        ref = oracle.psmnet_forward(sd, x, case["maxdisp"], recipes.out_hw(case), training=True)
+    for a, b in zip(got, ref):
+        assert float((a.cpu() - b).abs().max()) <= DISP_TOL
+
+
+def test_reference_checkpoint_keys_load(gpu):
+    """A DataParallel-style checkpoint ('module.' prefix, main_msnet.py:199-203) loads after prefix strip and
+    the plan cache notices the new weights."""
+    G, _ = _our_classes()
+    torch.manual_seed(0)
+    a = G(32).eval().cuda()
+    torch.manual_seed(1)
+    b = G(32).eval()
+    recipes.randomize_bn(b, 1)
+    x = torch.rand(1, 8, 16, 16, 32).cuda()
+    d0 = a(x).clone()
+    ckpt = {"module." + k: v for k, v in b.state_dict().items()}
+    a.load_state_dict({k[len("module."):]: v for k, v in ckpt.items()}, strict=True)
+    d1 = a(x)
+    with torch.no_grad():
+        ref = oracle.gcnet_forward(b.state_dict(), x.cpu(), 32)
+    assert float((d1.cpu() - ref).abs().max()) <= DISP_TOL
+    assert float((d1 - d0).abs().max()) > 1e-3
+
+
+def test_errors(gpu):
+    G, P = _our_classes()
+    m = G(32).cuda()
+    with pytest.raises(RuntimeError, match="inference only"):
+        m(torch.rand(1, 8, 16, 16, 32).cuda())
+    m.eval()
+    with pytest.raises(AssertionError):
+        m(torch.rand(1, 8, 32, 16, 32).cuda())          # 2*D' != maxdisp  (gcnet_3dcnn.py:135)
+    with pytest.raises(ValueError):
+        P(32).eval().cuda()(torch.rand(1, 8, 8, 16, 16).cuda())
