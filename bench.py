@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""Headline benchmark: disparity maps / second of the MS-GCNet cost-volume forward pass
+(BASELINE.json: "disparity maps/sec, 960x540 D=192 MS-GCNet fwd @1/2/4/8 GPU").
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One step = one pass of the hot path over one batch of synthetic stereo pairs already resident in HBM:
+  two bordered uint8 half-res images -> HIP matching-space volume [8,96,272,480] -> HIP MS-GCNet (19 3-D
+  convs on the fp32-input MFMA) -> fused deconv5+soft-argmin -> disparity [544,960]; for N>1 an RCCL all-gather
+  of the per-rank maps closes the step.  Weak scaling: every rank processes --batch-per-gpu pairs per step.
+
+Rank 0 prints ONE JSON line (contract in the task statement) extended with
+  roofline     : the dominant kernel (stride-1 MFMA conv3d) -- algorithmic FLOPs / HIP-event time, vs the
+                 155-157 TFLOP/s fp32-matrix peak of MI355X (MI355X_MICROARCH.md);
+  cpu_baseline : the CPU oracle (a port, not the reference binary) timed on this host on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)", spec; 155 measured
+WORKLOADS = {
+    # name: (padded H, W, maxdisp, description)
+    "cfg2": (544, 960, 192, "MS-GCNet forward (MS volume build + 19-conv aggregator + soft-argmin), Scene-Flow "
+                            "960x540 padded to 960x544, D=192"),
+    "cfg5": (384, 1248, 192, "MS-GCNet forward, KITTI 1242x375 padded to 1248x384, D=192"),
+    "cfg1": (256, 512, 64, "MS-GCNet forward, 256x512, D=64"),
+}
+
+
+def gcnet_flops(H, W, D):
+    """Algorithmic FLOPs of the 19 convs per map: 2 * 27 * Ci * Co * voxels."""
+    d, h, w = D // 2, H // 2, W // 2
+    v = [d * h * w // (8 ** k) for k in range(5)]
+    mac = 27 * (8 * 32 * v[0] + 32 * 32 * v[0])
+    chans = [(32, 64), (64, 64), (64, 64), (64, 128)]
+    for k, (ci, co) in enumerate(chans, start=1):
+        mac += 27 * (ci * co + 2 * co * co) * v[k]
+    for (ci, co, k) in [(128, 64, 4), (64, 64, 3), (64, 64, 2), (64, 32, 1), (32, 1, 0)]:
+        mac += 27 * ci * co * v[k]
+    return 2.0 * mac
+
+
+def cpu_baseline(seed=0):
+    """The oracle (CPU port of the same path: C matchers + NumPy glue + torch fp32 aggregator) on a bounded
+    sample: the cfg#2 depth (D'=96) on a 96x240 half-res crop (1/5.67 of the 272x480 voxels).  Throughput is
+    scaled to full maps by the voxel ratio (every stage is linear in H'*W')."""
+    from msnets_amd import synthetic
+    from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre
+    from oracle import aggregators, ms_volume
+    hs, ws, nd = 96, 240, 96
+    cores = min(os.cpu_count() or 1, 64)     # MKL-DNN conv3d stops scaling (and regresses) far below 256 threads
+    torch.set_num_threads(cores)
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    left, right, _ = synthetic.stereo_pair(hs, ws, nd, seed=seed)
+    torch.manual_seed(0)
+    sd = GCNet_CostVolumeAggre(2 * nd).eval().state_dict()
+    t0 = time.time()
+    vol = ms_volume.build_ms_volume(left, right, nd)
+    t1 = time.time()
+    with torch.no_grad():
+        aggregators.gcnet_forward(sd, torch.from_numpy(vol).unsqueeze(0), 2 * nd)
+    t2 = time.time()
+    scale = (272 * 480) / float(hs * ws)
+    return {"value": 1.0 / ((t2 - t0) * scale), "unit": "maps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "oracle volume build (%.1fs) + torch-CPU fp32 GCNet forward (%.1fs) on a %dx%d half-res crop "
+                      "at D'=96, scaled x%.2f to 272x480" % (t1 - t0, t2 - t1, hs, ws, scale)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-volume", action="store_true", help="aggregator only (random volume), not the headline")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    import msnets_amd
+    from msnets_amd import _lib, cbmv_generator, dist as msdist, synthetic
+    from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre
+
+    rank, world, local = msdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d: launch with torch.distributed.run" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; there is no CPU fallback for the product path")
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    _lib.load()
+
+    H, W, D, desc = WORKLOADS[args.workload]
+    hh, wh, nd = H // 2, W // 2, D // 2
+    B = args.batch_per_gpu
+    n_total = B * world
+
+    # synthetic inputs, resident in HBM before the timed region; sample i -> rank i % world
+    pairs = []
+    for i in msdist.shard_indices(n_total, rank, world):
+        l, r, _ = synthetic.stereo_pair(hh, wh, nd, seed=i)
+        pairs.append((torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev)))
+    torch.manual_seed(0)
+    model = GCNet_CostVolumeAggre(D).eval().to(dev)
+    builder = cbmv_generator.VolumeBuilder(hh + 20, wh + 20, nd, dev)
+    vol = torch.empty((B, 8, nd, hh, wh), device=dev, dtype=torch.float32)
+    if args.no_volume:
+        vol.copy_(synthetic.random_volume(tuple(vol.shape), seed=rank).to(dev))
+
+    def step():
+        if not args.no_volume:
+            for b, (l, r) in enumerate(pairs):
+                builder(l, r, out=vol[b])
+        disp = model(vol)
+        return msdist.gather_disparities(disp, n_total)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    assert out.shape == (n_total, H, W) and bool(torch.isfinite(out).all())
+
+    _lib.prof_enable(True)
+    msdist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    msdist.barrier()
+    dt = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    prof = _lib.prof_collect()
+
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        maps = n_total * args.steps
+        dom = prof.get("conv3d_s1", {"ms": 0.0, "flops": 0.0, "calls": 0})
+        achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
+        conv_ms = sum(v["ms"] for k, v in prof.items() if k.startswith(("conv3d", "deconv3d")))
+        conv_fl = sum(v["flops"] for k, v in prof.items() if k.startswith(("conv3d", "deconv3d")))
+        line = {
+            "metric": "disparity maps/sec, 960x540 D=192 MS-GCNet fwd",
+            "value": maps / dt, "unit": "maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": desc + ", batch=%d per GPU" % B, "global_batch": n_total,
+                       "parallelism": "dp%d (rank-sharded pairs, RCCL all-gather of disparity maps)" % world,
+                       "includes_volume_build": not args.no_volume},
+            "roofline": {"bound": "mfma", "kernel": "conv3d_k3_mfma (stride-1 launches)", "achieved": achieved,
+                         "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP32_MATRIX_PEAK_TFLOPS,
+                         "launches": dom["calls"], "avg_launch_ms": dom["ms"] / max(1, dom["calls"]),
+                         "all_conv_tflops": conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
+                         "traffic": None},
+        }
+        if args.verbose:
+            tot = sum(v["ms"] for v in prof.values())
+            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
+                tf = v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0
+                gb = v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0
+                print("  %-22s calls %4d  %9.3f ms/step (%5.1f%%)  %7.1f TFLOP/s  %8.1f GB/s(alg)" % (
+                    k, v["calls"], v["ms"] / args.steps, 100 * v["ms"] / tot, tf, gb), file=sys.stderr)
+            print("  kernels %.3f ms/step of %.3f ms/step wall" % (tot / args.steps, 1e3 * dt / args.steps), file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -66,6 +66,13 @@ int msnet_swap_axes(const float* in, float* out, int D, int H, int W, msnet_stre
 int msnet_extract_likelihood(const float* vol, float* out, long P, int D, float sigma,
                              msnet_stream_t stream);
 
+/* extract_features_left(census,ncc,sobel,sad,...) cbmv_generator.py:258-308 on the reference's row layout:
+ * four raw costs f32[P][D] (P = H'*W') -> out f32[8][D][P] = [8][D][H'][W']: channels 0-3 the clipped/normalised
+ * costs (:283-287), 4-7 their likelihoods (:301-304; the Sobel channel uses sad_sigma, as the reference does). */
+int msnet_extract_features_left(const float* census, const float* ncc, const float* sobel, const float* sad,
+                                float* out, long P, int D, float cens_sigma, float ncc_sigma, float sad_sigma,
+                                msnet_stream_t stream);
+
 /* ---- fused volume build: replaces get_costs + extract_features_left,
  *      src/dataloader/cbmv_generator.py:27-79 and :258-308 ------------------------------------- */
 typedef struct msnet_volume_params {

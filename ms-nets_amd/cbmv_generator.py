@@ -41,24 +41,19 @@ def get_costs(iml, imr, maxdisp=192, censw=11, nccw=3, sadw=5, sobelw=5, board_h
 
 def extract_features_left(census, ncc, sobel, sad, cens_sigma=128.0, ncc_sigma=0.02, sad_sigma=20000.0,
                           sobel_sigma=20000.0, disp_image=None):
-    """-> [8, ndisp, H', W'] float32.  The 4 normalisations are elementwise plumbing (torch / NumPy, float32,
-    the reference's own expressions); the 4 likelihood channels run in the HIP library.  As in the reference
-    the Sobel channel's likelihood uses sad_sigma and sobel_sigma is ignored (:298,303)."""
+    """-> [8, ndisp, H', W'] float32.  One C-ABI call (normalisation, likelihood and the [8,D,H,W] transpose all on the
+    device; torch's GPU divide-by-scalar is a reciprocal multiply and would not be bit-faithful).  As in the
+    reference the Sobel channel's likelihood uses sad_sigma and sobel_sigma is ignored (:298,303)."""
     was_numpy = isinstance(census, np.ndarray)
     if was_numpy:
         census, ncc, sobel, sad = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (census, ncc, sobel, sad))
     h, w, nd = census.shape
-    flat = lambda a: a.reshape(h * w, nd)   # noqa: E731
-    feats = torch.empty((8, h, w, nd), device=census.device, dtype=torch.float32)
-    feats[0] = torch.clamp(census, 0., 120.) / 120.
-    feats[1] = (1 + torch.clamp(ncc, -1., 1.)) / 2
-    feats[2] = torch.clamp(sobel, 0., 2. ** 13) / float(2 ** 13)
-    feats[3] = torch.clamp(sad, 0., 2. ** 13) / float(2 ** 13)
-    feats[4] = fte.extract_likelihood(flat(census), cens_sigma).reshape(h, w, nd)
-    feats[5] = fte.extract_likelihood(flat(ncc), ncc_sigma).reshape(h, w, nd)
-    feats[6] = fte.extract_likelihood(flat(sobel), sad_sigma).reshape(h, w, nd)
-    feats[7] = fte.extract_likelihood(flat(sad), sad_sigma).reshape(h, w, nd)
-    out = feats.permute(0, 3, 1, 2).contiguous()
+    ins = [_lib.require_gpu_f32(a, nm).reshape(h * w, nd) for a, nm in
+           ((census, "census"), (ncc, "ncc"), (sobel, "sobel"), (sad, "sad"))]
+    out = torch.empty((8, nd, h, w), device=ins[0].device, dtype=torch.float32)
+    check(_lib.load().msnet_extract_features_left(ptr(ins[0]), ptr(ins[1]), ptr(ins[2]), ptr(ins[3]), ptr(out), h * w, nd,
+                                                  float(cens_sigma), float(ncc_sigma), float(sad_sigma), stream_ptr()),
+          "msnet_extract_features_left")
     return out.cpu().numpy() if was_numpy else out
 
 

@@ -40,14 +40,14 @@ LaunchScope::LaunchScope(const char* n, hipStream_t s, double flops, double byte
     if (!g_prof) return;
     Rec* r = new Rec{n, nullptr, nullptr, flops, bytes};
     if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return; }
-    hipEventRecord(r->a, s);
+    (void)hipEventRecord(r->a, s);
     rec = r;
 }
 
 LaunchScope::~LaunchScope() {
     if (!rec) return;
     Rec* r = static_cast<Rec*>(rec);
-    hipEventRecord(r->b, stream);
+    (void)hipEventRecord(r->b, stream);
     std::lock_guard<std::mutex> lk(g_mu);
     g_recs.push_back(r);
 }
@@ -78,8 +78,8 @@ extern "C" long msnet_prof_collect(char* buf, size_t n) {
             Agg& g = agg[r->name];
             g.calls++; g.ms += ms; g.flops += r->flops; g.bytes += r->bytes;
         }
-        hipEventDestroy(r->a);
-        hipEventDestroy(r->b);
+        (void)hipEventDestroy(r->a);
+        (void)hipEventDestroy(r->b);
         delete r;
     }
     size_t off = 0;

@@ -98,10 +98,10 @@ static int layout_common(bool to_cl, const float* src, float* dst, int N, int C,
     dim3 grid((unsigned)((S + 255) / 256), (unsigned)N);
     LaunchScope ls(to_cl ? "ncdhw_to_ndhwc" : "ndhwc_to_ncdhw", s, 0, 8.0 * N * C * (double)S);
     if (to_cl) {
-        if (lds > 65536) hipFuncSetAttribute((const void*)ncs_to_nsc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 65536) (void)hipFuncSetAttribute((const void*)ncs_to_nsc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(ncs_to_nsc_kernel, grid, dim3(256), lds, s, src, dst, C, S);
     } else {
-        if (lds > 65536) hipFuncSetAttribute((const void*)nsc_to_ncs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (lds > 65536) (void)hipFuncSetAttribute((const void*)nsc_to_ncs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(nsc_to_ncs_kernel, grid, dim3(256), lds, s, src, dst, C, S);
     }
     return check_launch("msnet layout");

@@ -17,14 +17,14 @@ struct SoftArg {
     __device__ __forceinline__ void init() { m = -INFINITY; s = 0.f; t = 0.f; }
     __device__ __forceinline__ void push(float x, float d) {
         const float mn = fmaxf(m, x);
-        const float a = __expf(m - mn), e = __expf(x - mn);
+        const float a = expf(m - mn), e = expf(x - mn);
         s = s * a + e;
         t = t * a + d * e;
         m = mn;
     }
     __device__ __forceinline__ void push2(float x0, float d0, float x1, float d1) {
         const float mn = fmaxf(m, fmaxf(x0, x1));
-        const float a = __expf(m - mn), e0 = __expf(x0 - mn), e1 = __expf(x1 - mn);
+        const float a = expf(m - mn), e0 = expf(x0 - mn), e1 = expf(x1 - mn);
         s = s * a + e0 + e1;
         t = t * a + d0 * e0 + d1 * e1;
         m = mn;

@@ -268,6 +268,33 @@ __global__ __launch_bounds__(64) void aml_rows_kernel(const float* __restrict__ 
     for (int k = lane; k < n * D; k += 64) out[base + k] = rows[(k / D) * LS + k % D];
 }
 
+// extract_features_left for ONE matcher on the reference's row layout: vol [P][D] (P = H'*W' pixels) ->
+//   out_cost[d][p] = normalised cost, out_aml[d][p] = likelihood  (i.e. already transposed to [D][H'][W']).
+__device__ __forceinline__ float normalise_cost(int ch, float c);
+__global__ __launch_bounds__(64) void features_rows_kernel(const float* __restrict__ vol, float* __restrict__ out_cost,
+                                                           float* __restrict__ out_aml, long P, int D, float sigma, int ch) {
+    extern __shared__ float rows[];   // [64][D+1]
+    const int lane = threadIdx.x;
+    const long p0 = (long)blockIdx.x * 64;
+    const int n = (int)((P - p0 < 64) ? (P - p0) : 64);
+    const int LS = D + 1;
+    const size_t base = (size_t)p0 * D;
+    for (int k = lane; k < n * D; k += 64) rows[(k / D) * LS + k % D] = vol[base + k];
+    __syncthreads();
+    if (lane < n) {
+        const float* rp = rows + lane * LS;
+        float m = kSentinel;
+        for (int k = 0; k < D; ++k) if (rp[k] < m) m = rp[k];
+        float den = 0.f;
+        for (int k = 0; k < D; ++k) den += aml_term(rp[k], m, sigma);
+        for (int k = 0; k < D; ++k) {
+            const float c = rp[k];
+            out_cost[(size_t)k * P + p0 + lane] = normalise_cost(ch, c);
+            out_aml[(size_t)k * P + p0 + lane] = (m == kSentinel) ? 0.f : aml_term(c, m, sigma) / den;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- assembly -----------------------------
 // extract_features_left on d-major raw costs [nd][Hb][Wb]: crop the border, write
 //   out[ch][d][y][x]    = normalised cost     (ch 0..3 = census, ncc, sobel-SAD, zsad)
@@ -429,10 +456,28 @@ extern "C" int msnet_extract_likelihood(const float* vol, float* out, long P, in
     const size_t lds = (size_t)64 * (D + 1) * sizeof(float);
     if (lds > 160 * 1024) return fail("msnet_extract_likelihood: D=%d too large for one LDS tile", D);
     hipStream_t s = (hipStream_t)stream;
-    if (lds > 65536) hipFuncSetAttribute((const void*)aml_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)aml_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     LaunchScope ls("extract_likelihood", s, 0, 8.0 * P * (double)D);
     hipLaunchKernelGGL(aml_rows_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), lds, s, vol, out, P, D, sigma);
     return check_launch("msnet_extract_likelihood");
+}
+
+extern "C" int msnet_extract_features_left(const float* census, const float* ncc, const float* sobel, const float* sad,
+                                           float* out, long P, int D, float cens_sigma, float ncc_sigma, float sad_sigma,
+                                           msnet_stream_t stream) {
+    if (!census || !ncc || !sobel || !sad || !out) return fail("msnet_extract_features_left: null pointer");
+    if (P <= 0 || D <= 0) return fail("msnet_extract_features_left: empty volume");
+    const size_t lds = (size_t)64 * (D + 1) * sizeof(float);
+    if (lds > 160 * 1024) return fail("msnet_extract_features_left: D=%d too large for one LDS tile", D);
+    hipStream_t s = (hipStream_t)stream;
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)features_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const float* in[4] = {census, ncc, sobel, sad};
+    const float sg[4] = {cens_sigma, ncc_sigma, sad_sigma, sad_sigma};
+    LaunchScope ls("features_rows", s, 0, 4.0 * 12.0 * P * (double)D);
+    for (int ch = 0; ch < 4; ++ch)
+        hipLaunchKernelGGL(features_rows_kernel, dim3((unsigned)((P + 63) / 64)), dim3(64), lds, s, in[ch],
+                           out + (size_t)ch * D * P, out + (size_t)(4 + ch) * D * P, P, D, sg[ch], ch);
+    return check_launch("msnet_extract_features_left");
 }
 
 extern "C" void msnet_volume_default_params(msnet_volume_params* p) {

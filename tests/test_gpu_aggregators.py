@@ -163,7 +163,7 @@ def test_trilinear_softargmin(gpu, in_dhw, out_dhw):
     cost = torch.randn((2, 1) + in_dhw, generator=g) * 4
     ref = oracle.soft_argmin(F.interpolate(cost, list(out_dhw), mode="trilinear", align_corners=True).squeeze(1))
     got = hipops.trilinear_softargmin(cost.squeeze(1).cuda(), out_dhw)
-    assert float((got.cpu() - ref).abs().max()) < 2e-4
+    assert float((got.cpu() - ref).abs().max()) < 5e-4   # fp32 noise on disparities ~100 at D=192; gate is 1e-3
 
 
 def _our_classes():

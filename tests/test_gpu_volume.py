@@ -1,0 +1,135 @@
+"""GPU parity of the matching-space volume kernels against the CPU oracle, through the libmatchers /
+libfeatextract / cbmv_generator mirrors (which call the C ABI).  Integer and order-pinned float32 paths must be
+bit-exact; the AML channels go through expf (GPU libm vs glibc) and get a 2e-6 abs tolerance on values in [0,1]."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ms_volume as O
+
+pytestmark = pytest.mark.gpu
+SENT = np.float32(2147483648.0)
+
+
+def _pair(H, W, nd, seed, kind="texture"):
+    from msnets_amd import synthetic
+    if kind == "texture":
+        l, r, _ = synthetic.stereo_pair(H - 20, W - 20, nd, seed=seed)
+        return l, r
+    rng = np.random.default_rng(seed)
+    if kind == "random":
+        return rng.integers(0, 256, (H, W), dtype=np.uint8), rng.integers(0, 256, (H, W), dtype=np.uint8)
+    if kind == "flat":      # large constant regions: NCC's non-finite branch, all-equal census
+        l = np.full((H, W), 90, np.uint8); r = np.full((H, W), 90, np.uint8)
+        l[: H // 2, : W // 2] = rng.integers(0, 256, (H // 2, W // 2), dtype=np.uint8)
+        r[H // 3:, W // 3:] = rng.integers(0, 256, (H - H // 3, W - W // 3), dtype=np.uint8)
+        return l, r
+    if kind == "extreme":   # 0/255 checkerboards: largest Sobel responses, float32 integral beyond 2^24
+        yy, xx = np.mgrid[0:H, 0:W]
+        l = (((yy + xx) & 1) * 255).astype(np.uint8)
+        r = (((yy + 2 * xx) & 1) * 255).astype(np.uint8)
+        return l, r
+    raise ValueError(kind)
+
+
+CASES = [(68, 100, 16, 0, "texture"), (48, 80, 16, 1, "random"), (57, 93, 12, 2, "flat"), (40, 150, 33, 3, "extreme"),
+         (30, 41, 8, 4, "random"), (12, 13, 4, 5, "random"), (292, 500, 96, 6, "texture")]
+
+
+def _bitexact(a, b, what):
+    a = np.asarray(a); b = np.asarray(b)
+    assert a.shape == b.shape and a.dtype == b.dtype, what
+    bad = a.view(np.uint32) != b.view(np.uint32)
+    assert not bad.any(), "%s: %d / %d values differ, max|diff| %.3e" % (
+        what, int(bad.sum()), bad.size, float(np.abs(a[bad].astype(np.float64) - b[bad]).max()))
+
+
+@pytest.mark.parametrize("H,W,nd,seed,kind", CASES)
+def test_matchers_bit_exact(gpu, H, W, nd, seed, kind):
+    from msnets_amd import libmatchers as mtc, libfeatextract as fte
+    l, r = _pair(H, W, nd, seed, kind)
+    _bitexact(mtc.census(l, r, nd, 11), O.census(l, r, nd, 11), "census")
+    _bitexact(mtc.nccNister(l, r, nd, 3), O.nccNister(l, r, nd, 3), "ncc")
+    _bitexact(mtc.zsad(l, r, nd, 5), O.zsad(l, r, nd, 5), "zsad")
+    sl, sr = mtc.sobel(l), mtc.sobel(r)
+    _bitexact(sl, O.sobel(l), "sobel")
+    _bitexact(mtc.sadsob(sl, sr, nd, 5), O.sadsob(O.sobel(l), O.sobel(r), nd, 5), "sadsob")
+    z = O.zsad(l, r, nd, 5)
+    _bitexact(fte.swap_axes(z), O.swap_axes(z), "swap_axes")
+
+
+def test_other_window_sizes(gpu):
+    from msnets_amd import libmatchers as mtc
+    l, r = _pair(50, 70, 10, 7, "random")
+    _bitexact(mtc.census(l, r, 10, 5), O.census(l, r, 10, 5), "census w5")
+    _bitexact(mtc.census(l, r, 10, 9), O.census(l, r, 10, 9), "census w9")
+    _bitexact(mtc.nccNister(l, r, 10, 5), O.nccNister(l, r, 10, 5), "ncc w5")
+    _bitexact(mtc.zsad(l, r, 10, 3), O.zsad(l, r, 10, 3), "zsad w3")
+    s = O.sobel(l), O.sobel(r)
+    _bitexact(mtc.sadsob(s[0], s[1], 10, 7), O.sadsob(s[0], s[1], 10, 7), "sadsob w7")
+
+
+@pytest.mark.parametrize("sigma", [128.0, 0.02, 20000.0])
+def test_extract_likelihood(gpu, sigma):
+    from msnets_amd import libfeatextract as fte
+    rng = np.random.default_rng(0)
+    vol = (rng.random((1000, 96), dtype=np.float32) * {128.0: 120, 0.02: 2, 20000.0: 8192}[sigma]).astype(np.float32)
+    vol[rng.random(vol.shape) < 0.2] = SENT          # unreached entries
+    vol[5] = SENT                                      # an all-sentinel row -> zeros
+    got, ref = fte.extract_likelihood(vol, sigma), O.extract_likelihood(vol, sigma)
+    assert np.abs(got - ref).max() <= 2e-6
+    assert not got[5].any()
+    assert np.all(got[vol == SENT] == 0)
+    live = np.ones(len(vol), bool); live[5] = False
+    assert np.abs(got[live].sum(1) - 1).max() < 1e-4
+
+
+@pytest.mark.parametrize("H,W,nd,seed,kind", CASES[:5] + CASES[6:])
+def test_fused_volume_build(gpu, H, W, nd, seed, kind):
+    """msnet_build_volume == get_costs + extract_features_left of the oracle; cost channels bit-exact."""
+    from msnets_amd import cbmv_generator as cg
+    l, r = _pair(H, W, nd, seed, kind)
+    ref = O.build_ms_volume(l, r, nd)
+    got = cg.build_ms_volume(l, r, nd)
+    assert got.shape == ref.shape == (8, nd, H - 20, W - 20)
+    for ch, nm in enumerate(["census", "ncc", "sobel", "sad"]):
+        _bitexact(got[ch], ref[ch], "cost channel " + nm)
+    assert np.abs(got[4:] - ref[4:]).max() <= 2e-6
+    assert got.min() >= 0 and got.max() <= 1
+
+
+def test_unfused_pipeline_matches_fused(gpu):
+    """The reference's own call sequence (get_costs -> extract_features_left) through the drop-in modules."""
+    from msnets_amd import cbmv_generator as cg
+    l, r = _pair(68, 100, 16, 0, "texture")
+    costs = cg.get_costs(l, r, 16, 11, 3, 5, 5, 10, 10, 10)
+    ref_costs = O.get_costs(l, r, 16, 11, 3, 5, 5, 10, 10, 10)
+    for a, b, nm in zip(costs, ref_costs, ["census", "ncc", "sobel", "sad"]):
+        _bitexact(a, b, nm)
+    feats = cg.extract_features_left(*costs)
+    fused = cg.build_ms_volume(l, r, 16)
+    _bitexact(feats[:4], fused[:4], "cost channels fused vs unfused")
+    assert np.abs(feats[4:] - fused[4:]).max() <= 2e-6
+
+
+def test_planted_disparity_recovered(gpu):
+    """Size-independent property at a benchmark shape: census argmin recovers the planted shift."""
+    from msnets_amd import cbmv_generator as cg, synthetic
+    l, r, drows = synthetic.stereo_pair(128, 256, 32, seed=3)
+    vol = cg.build_ms_volume(torch.from_numpy(l).cuda(), torch.from_numpy(r).cuda(), 32)
+    am = vol[0].argmin(0).cpu().numpy()                  # [H', W']
+    ok = am[:, 40:] == drows[:, None]
+    assert ok.mean() > 0.9
+    aml = vol[4].cpu().numpy()
+    assert np.abs(aml.sum(0) - 1).max() < 1e-4           # likelihoods sum to 1 over d wherever a cost exists
+
+
+def test_volume_errors(gpu):
+    from msnets_amd import libmatchers as mtc
+    l, r = _pair(30, 40, 8, 0, "random")
+    with pytest.raises(TypeError):
+        mtc.census(l.astype(np.float32), r.astype(np.float32), 8, 11)
+    with pytest.raises(RuntimeError, match="wsize"):
+        mtc.census(l, r, 8, 4)
+    with pytest.raises(ValueError):
+        mtc.zsad(l, r[:, :-1].copy(), 8, 5)
