@@ -80,6 +80,51 @@ __device__ __forceinline__ void load_b(f32x4 (&b)[NB], const f32x4* __restrict__
     for (int j = 0; j < NB; ++j) b[j] = p[j * 64];
 }
 
+// Epilogue of one 32x32 accumulator block: y = act(acc*scale + shift (+ residual)).  For accumulator register e
+// the 32 lanes of a half hold the 32 channels of ONE voxel (two full 128-byte lines per store instruction).
+// Voxel of (e, half hh): local row = c_e + 4*hh with c_e = (e&3) + 8*(e>>2); because c_e % BW is in 0..3 (+8k) the
+// 4*hh never carries into the h index, so the offset splits into a lane-dependent base (folded into `base` by the
+// caller) plus compile-time multiples of two uniform strides.  FULL tiles take the branch-free path: all residual
+// loads are issued before the first use (the naive per-element form serialised 16 dependent HBM round trips per
+// block and ran the transposed convs at 30 TFLOP/s, profiles/r01b).
+template <int BW, class Valid>
+__device__ __forceinline__ void epilogue_block(const f32x16& acc, float sc, float sh, const float* __restrict__ res,
+                                               float* __restrict__ y, size_t base, int stride_h, int stride_w, int relu,
+                                               bool full, Valid valid) {
+    if (full) {
+        float rv[16];
+        if (res) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = (e & 3) + 8 * (e >> 2);
+                rv[e] = res[base + (size_t)((c / BW) * stride_h + (c % BW) * stride_w)];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = (e & 3) + 8 * (e >> 2);
+            float v = acc[e] * sc + sh + rv[e];
+            if (relu) v = fmaxf(v, 0.f);
+            y[base + (size_t)((c / BW) * stride_h + (c % BW) * stride_w)] = v;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = (e & 3) + 8 * (e >> 2);
+            if (valid(c / BW, c % BW)) {
+                const size_t idx = base + (size_t)((c / BW) * stride_h + (c % BW) * stride_w);
+                float v = acc[e] * sc + sh;
+                if (res) v += res[idx];
+                if (relu) v = fmaxf(v, 0.f);
+                y[idx] = v;
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Forward conv, kernel 3, pad 1, stride STRIDE.
 //   tile: TD x TH x TW output voxels = WM*MB M-blocks of (32/BW) x BW voxels; WN*NB N-blocks.
@@ -138,59 +183,60 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma(ConvArgs a) {
         const size_t wtap = (size_t)nci8 * a.nbtot * 64;
         const size_t wq = (size_t)a.nbtot * 64;
 
-        f32x4 bq[2][NQ][NB];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) load_b<NB>(bq[0][q], wbase + q * wq);
-
-#pragma unroll
-        for (int tap = 0; tap < 27; ++tap) {
+        // Software pipeline over the S = 27*NQ (tap, q) steps: the A fragments (LDS) run one step ahead, the B
+        // fragments (L2) two steps ahead, in statically indexed register rings; sched_barrier pins "issue the
+        // prefetches, then the MFMA block" -- left alone, hipcc sinks every load to just before its first use and
+        // exposes the full L2 latency once per step (profiles/r01a: 78 TFLOP/s).
+        constexpr int S = 27 * NQ;
+        f32x4 av[2][MB], bv[3][NB];
+        auto a_load = [&](f32x4 (&dst)[MB], int st) {
+            const int tap = st / NQ, q = st % NQ;
             const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            const int toff = ((kd * IH + kh) * IW + kw) * PS;
-            if (tap + 1 < 27) {
+            const int toff = ((kd * IH + kh) * IW + kw) * PS + q * 8;
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) load_b<NB>(bq[(tap + 1) & 1][q], wbase + (tap + 1) * wtap + q * wq);
-            }
+            for (int i = 0; i < MB; ++i) dst[i] = *reinterpret_cast<const f32x4*>(lds + abase[i] + toff);
+        };
+        auto b_load = [&](f32x4 (&dst)[NB], int st) {
+            const int tap = st / NQ, q = st % NQ;
+            load_b<NB>(dst, wbase + tap * wtap + q * wq);
+        };
+        b_load(bv[0], 0);
+        if (S > 1) b_load(bv[1], 1);
+        a_load(av[0], 0);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                f32x4 av[MB];
+        for (int st = 0; st < S; ++st) {
+            if (st + 2 < S) b_load(bv[(st + 2) % 3], st + 2);
+            if (st + 1 < S) a_load(av[(st + 1) & 1], st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
-                    av[i] = *reinterpret_cast<const f32x4*>(lds + abase[i] + toff + q * 8);
 #pragma unroll
-                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                    for (int i = 0; i < MB; ++i)
-#pragma unroll
-                        for (int j = 0; j < NB; ++j)
-                            acc[i][j] = mfma32(av[i][t], bq[tap & 1][q][j][t], acc[i][j]);
-            }
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = mfma32(av[st & 1][i][t], bv[st % 3][j][t], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
-    // Epilogue: BN affine (+ skip) (+ ReLU); for one accumulator register the 32 lanes of a half hold the
-    // 32 channels of one voxel => each store instruction writes two full 128-byte lines.
+    // Epilogue: BN affine (+ skip) (+ ReLU).
+    const bool full_hw = (oh0 + TH <= a.OH) && (ow0 + TW <= a.OW);
+    const int stride_w = a.Co, stride_h = a.OW * a.Co;
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
         const int mb = wm * MB + i;
         const int bw = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
         const int od = od0 + bd;
+        if (od >= a.OD) continue;
+        const int ohb = oh0 + bh * BH, owb = ow0 + bw * BW + 4 * hh;      // voxel of (c_e = 0, half hh)
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int co = (nb0 + j) * 32 + r;
             const float sc = a.scale ? a.scale[co] : 1.f;
             const float sh = a.shift ? a.shift[co] : 0.f;
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
-                const int oh = oh0 + bh * BH + row / BW, ow = ow0 + bw * BW + row % BW;
-                if (od < a.OD && oh < a.OH && ow < a.OW) {
-                    const size_t idx = ((((size_t)n * a.OD + od) * a.OH + oh) * a.OW + ow) * a.Co + co;
-                    float v = acc[i][j][e] * sc + sh;
-                    if (a.res) v += a.res[idx];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    a.y[idx] = v;
-                }
-            }
+            const size_t base = ((((size_t)n * a.OD + od) * a.OH + ohb) * a.OW + owb) * a.Co + co;
+            epilogue_block<BW>(acc[i][j], sc, sh, a.res, a.y, base, stride_h, stride_w, a.relu, full_hw,
+                               [&](int lh, int lw) { return ohb + lh < a.OH && owb + lw < a.OW; });
         }
     }
 }
@@ -203,6 +249,80 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma(ConvArgs a) {
 // The whole Ci is resident in LDS (no chunk loop) so classes can be finished one after another with a
 // single live accumulator set.  Weights use the same packed order, indexed by the ConvTranspose3d tap.
 // ---------------------------------------------------------------------------------------------
+// One output-parity class (PD,PH,PW) of the transposed conv for this wave's MB x NB blocks: accumulate its
+// 2^(PD+PH+PW) taps from the LDS tile, then run the epilogue.  Steps (delta, q) use the same software pipeline
+// as the forward conv (A one step ahead, B two steps ahead, sched_barrier-pinned).
+template <int CI, int IH, int IW, int BW, int MH, int MW, int MB, int NB, int PD, int PH, int PW>
+__device__ __forceinline__ void deconv_class(const float* lds, const int (&abase)[MB], const f32x4* __restrict__ wbase,
+                                             size_t wtap, size_t wq, const ConvArgs& a, int n, int d0, int h0, int w0,
+                                             int wm, int nb0, int r, int hh) {
+    constexpr int BH = 32 / BW, PS = CI + 4, NQ = CI / 8;
+    constexpr int NT = (PD + 1) * (PH + 1) * (PW + 1);
+    constexpr int S = NT * NQ;
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 av[2][MB], bv[3][NB];
+    auto a_load = [&](f32x4 (&dst)[MB], int st) {
+        const int tp = st / NQ, q = st % NQ;
+        const int dw = tp % (PW + 1), dh = (tp / (PW + 1)) % (PH + 1), dd = tp / ((PW + 1) * (PH + 1));
+        const int toff = ((dd * IH + dh) * IW + dw) * PS + q * 8;
+#pragma unroll
+        for (int i = 0; i < MB; ++i) dst[i] = *reinterpret_cast<const f32x4*>(lds + abase[i] + toff);
+    };
+    auto b_load = [&](f32x4 (&dst)[NB], int st) {
+        const int tp = st / NQ, q = st % NQ;
+        const int dw = tp % (PW + 1), dh = (tp / (PW + 1)) % (PH + 1), dd = tp / ((PW + 1) * (PH + 1));
+        const int kd = PD ? (dd ? 0 : 2) : 1;
+        const int kh = PH ? (dh ? 0 : 2) : 1;
+        const int kw = PW ? (dw ? 0 : 2) : 1;
+        load_b<NB>(dst, wbase + ((kd * 3 + kh) * 3 + kw) * wtap + q * wq);
+    };
+    b_load(bv[0], 0);
+    if (S > 1) b_load(bv[1], 1);
+    a_load(av[0], 0);
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+        if (st + 2 < S) b_load(bv[(st + 2) % 3], st + 2);
+        if (st + 1 < S) a_load(av[(st + 1) & 1], st + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    acc[i][j] = mfma32(av[st & 1][i][t], bv[st % 3][j][t], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    constexpr int TH_ = MH * BH, TW_ = MW * BW;
+    const bool full_hw = (h0 + TH_ <= a.H) && (w0 + TW_ <= a.W);
+    const int stride_w = 2 * a.Co, stride_h = 2 * a.OW * a.Co;
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int mb = wm * MB + i;
+        const int bw = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
+        const int id = d0 + bd;
+        if (id >= a.D) continue;
+        const int ihb = h0 + bh * BH, iwb = w0 + bw * BW + 4 * hh;        // input voxel of (c_e = 0, half hh)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int co = (nb0 + j) * 32 + r;
+            const float sc = a.scale ? a.scale[co] : 1.f;
+            const float sh = a.shift ? a.shift[co] : 0.f;
+            const size_t base = ((((size_t)n * a.OD + 2 * id + PD) * a.OH + 2 * ihb + PH) * a.OW + 2 * iwb + PW) * a.Co + co;
+            epilogue_block<BW>(acc[i][j], sc, sh, a.res, a.y, base, stride_h, stride_w, a.relu, full_hw,
+                               [&](int lh, int lw) { return ihb + lh < a.H && iwb + lw < a.W; });
+        }
+    }
+}
+
 template <int CI, int TD, int TH, int TW, int BW, int WM, int WN, int MB, int NB>
 __global__ __launch_bounds__(256, 1) void deconv3d_k3s2_mfma(ConvArgs a) {
     constexpr int BH = 32 / BW;
@@ -242,73 +362,17 @@ __global__ __launch_bounds__(256, 1) void deconv3d_k3s2_mfma(ConvArgs a) {
     const size_t wq = (size_t)a.nbtot * 64;
     const f32x4* wbase = a.wpk + (size_t)nb0 * 64 + lane;
 
-#pragma unroll
-    for (int cls = 0; cls < 8; ++cls) {
-        const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
-        f32x16 acc[MB][NB];
-#pragma unroll
-        for (int i = 0; i < MB; ++i)
-#pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-#pragma unroll
-        for (int dd = 0; dd <= pd; ++dd)
-#pragma unroll
-            for (int dh = 0; dh <= ph; ++dh)
-#pragma unroll
-                for (int dw = 0; dw <= pw; ++dw) {
-                    const int kd = pd ? (dd ? 0 : 2) : 1;
-                    const int kh = ph ? (dh ? 0 : 2) : 1;
-                    const int kw = pw ? (dw ? 0 : 2) : 1;
-                    const int tap = (kd * 3 + kh) * 3 + kw;
-                    const int toff = ((dd * IH + dh) * IW + dw) * PS;
-                    const f32x4* wp = wbase + tap * wtap;
-#pragma unroll 4
-                    for (int q = 0; q < NQ; ++q) {
-                        f32x4 bv[NB];
-                        load_b<NB>(bv, wp + q * wq);
-                        f32x4 av[MB];
-#pragma unroll
-                        for (int i = 0; i < MB; ++i)
-                            av[i] = *reinterpret_cast<const f32x4*>(lds + abase[i] + toff + q * 8);
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-#pragma unroll
-                            for (int i = 0; i < MB; ++i)
-#pragma unroll
-                                for (int j = 0; j < NB; ++j)
-                                    acc[i][j] = mfma32(av[i][t], bv[j][t], acc[i][j]);
-                    }
-                }
-
-#pragma unroll
-        for (int i = 0; i < MB; ++i) {
-            const int mb = wm * MB + i;
-            const int bw = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
-            const int id = d0 + bd;
-#pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int co = (nb0 + j) * 32 + r;
-                const float sc = a.scale ? a.scale[co] : 1.f;
-                const float sh = a.shift ? a.shift[co] : 0.f;
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = (e & 3) + 8 * (e >> 2) + 4 * hh;
-                    const int ih = h0 + bh * BH + row / BW, iw = w0 + bw * BW + row % BW;
-                    if (id < a.D && ih < a.H && iw < a.W) {
-                        const int od = 2 * id + pd, oh = 2 * ih + ph, ow = 2 * iw + pw;
-                        const size_t idx = ((((size_t)n * a.OD + od) * a.OH + oh) * a.OW + ow) * a.Co + co;
-                        float v = acc[i][j][e] * sc + sh;
-                        if (a.res) v += a.res[idx];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        a.y[idx] = v;
-                    }
-                }
-            }
-        }
-    }
+#define MSNET_DECONV_CLASS(PD, PH, PW) \
+    deconv_class<CI, IH, IW, BW, MH, MW, MB, NB, PD, PH, PW>(lds, abase, wbase, wtap, wq, a, n, d0, h0, w0, wm, nb0, r, hh)
+    MSNET_DECONV_CLASS(1, 1, 1);   // heaviest class first
+    MSNET_DECONV_CLASS(1, 1, 0);
+    MSNET_DECONV_CLASS(1, 0, 1);
+    MSNET_DECONV_CLASS(0, 1, 1);
+    MSNET_DECONV_CLASS(1, 0, 0);
+    MSNET_DECONV_CLASS(0, 1, 0);
+    MSNET_DECONV_CLASS(0, 0, 1);
+    MSNET_DECONV_CLASS(0, 0, 0);
+#undef MSNET_DECONV_CLASS
 }
 
 // ---------------------------------------------------------------------------------------------
