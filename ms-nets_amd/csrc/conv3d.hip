@@ -24,6 +24,17 @@
 
 namespace msnet {
 
+static int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
 struct ConvArgs {
     const float* x; const f32x4* wpk; const float* scale; const float* shift; const float* res; float* y;
     int N, D, H, W;        // input spatial dims
@@ -241,6 +252,187 @@ __global__ __launch_bounds__(256, 1) void conv3d_k3_mfma(ConvArgs a) {
     }
 }
 
+// LDS-only workgroup barrier: orders LDS traffic across the s_barrier without draining the vector-memory
+// counter (a plain __syncthreads() may add s_waitcnt vmcnt(0), which would stall the compute waves on their
+// in-flight weight loads and the loader waves on nothing useful).
+#define MSNET_LDS_BARRIER()                                              \
+    do {                                                                 \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  \
+        __builtin_amdgcn_s_barrier();                                    \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");  \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// Wave-specialised, persistent form of the forward conv (the one the big layers use).
+//   8 waves per workgroup, two per SIMD: waves 0-3 ("compute") run the software-pipelined MFMA loop and the
+//   epilogue exactly as conv3d_k3_mfma does; waves 4-7 ("loaders") fetch the NEXT work item's input tile from
+//   HBM/L2 into registers while the MFMAs run, then drop it into LDS between two barriers:
+//        loader :  issue(k) ... wait        |A_k| write LDS |B_k| issue(k+1) ...
+//        compute:  MFMA(k-1)                |A_k| epilogue(k-1) |B_k| MFMA(k) ...
+//   so the global-load latency of the tile hides under the previous item's MFMAs and the LDS fill hides under
+//   its epilogue.  The loaders have their own vmcnt, so their 20-odd outstanding tile loads never sit in front
+//   of the compute waves' counted waits on the weight stream.
+//   A workgroup walks work items (tile, Ci-chunk); tiles are dealt so that at any moment the 256 resident
+//   workgroups cover one contiguous run of tiles, split per XCD (halo re-reads hit that XCD's L2).
+// ---------------------------------------------------------------------------------------------
+template <int CC, int STRIDE, int TD, int TH, int TW, int BW, int WM, int WN, int MB, int NB>
+__global__ __launch_bounds__(512, 2) void conv3d_k3_mfma_ws(ConvArgs a) {
+    constexpr int BH = 32 / BW;
+    constexpr int ID = (TD - 1) * STRIDE + 3, IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
+    constexpr int PS = CC + 4;
+    constexpr int NQ = CC / 8;
+    constexpr int MW = TW / BW, MH = TH / BH;
+    constexpr int V = CC / 4;
+    constexpr int NSLOT = ID * IH * IW * V;
+    constexpr int NL = (NSLOT + 255) / 256;            // float4 per loader thread
+    static_assert(TD * MH * MW == WM * MB, "M-block count mismatch");
+    static_assert(WM * WN == 4, "4 compute waves per workgroup");
+    __shared__ __attribute__((aligned(16))) float lds[ID * IH * IW * PS];
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const unsigned G = gridDim.x;
+    const unsigned lb = xcd_remap(blockIdx.x, G);
+    const int nchunks = a.Ci / CC;
+    const unsigned T = (unsigned)a.N * a.ntd * a.nth * a.ntw * a.ngroups;
+    const int my_tiles = (T > lb) ? (int)((T - lb + G - 1) / G) : 0;
+    const int nitems = my_tiles * nchunks;
+    if (nitems == 0) return;
+
+    auto decode = [&](int it, int& g, int& n, int& od0, int& oh0, int& ow0, int& chunk) {
+        unsigned t = lb + (unsigned)(it / nchunks) * G;
+        chunk = it % nchunks;
+        g = t % a.ngroups; t /= a.ngroups;
+        ow0 = (t % a.ntw) * TW; t /= a.ntw;
+        oh0 = (t % a.nth) * TH; t /= a.nth;
+        od0 = (t % a.ntd) * TD;
+        n = t / a.ntd;
+    };
+
+    if (wave >= 4) {
+        // ------------------------------ loader waves ------------------------------
+        const int lt = tid - 256;
+        for (int it = 0; it < nitems; ++it) {
+            int g, n, od0, oh0, ow0, chunk;
+            decode(it, g, n, od0, oh0, ow0, chunk);
+            const int id0 = od0 * STRIDE - 1, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
+            const float* xc = a.x + chunk * CC;
+            f32x4 v[NL];
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const int slot = u * 256 + lt;
+                const int pos = slot / V, c4 = slot % V;
+                const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
+                const int gd = id0 + id, gh = ih0 + ih, gw = iw0 + iw;
+                v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (slot < NSLOT && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H &&
+                    (unsigned)gw < (unsigned)a.W) {
+                    const size_t vox = (((size_t)n * a.D + gd) * a.H + gh) * a.W + gw;
+                    v[u] = *reinterpret_cast<const f32x4*>(xc + vox * a.Ci + c4 * 4);
+                }
+            }
+            MSNET_LDS_BARRIER();                       // A_it: compute waves are done reading the previous tile
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const int slot = u * 256 + lt;
+                if (slot < NSLOT) *reinterpret_cast<f32x4*>(lds + (slot / V) * PS + (slot % V) * 4) = v[u];
+            }
+            MSNET_LDS_BARRIER();                       // B_it: tile is in LDS
+        }
+        return;
+    }
+
+    // ------------------------------ compute waves ------------------------------
+    const int wm = wave % WM, wn = wave / WM;
+    const int r = lane & 31, hh = lane >> 5;
+    int abase[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int mb = wm * MB + i;
+        const int bw = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
+        const int lh = bh * BH + r / BW, lw = bw * BW + r % BW;
+        abase[i] = ((bd * STRIDE * IH + lh * STRIDE) * IW + lw * STRIDE) * PS + 4 * hh;
+    }
+    const int nci8 = a.Ci >> 3;
+    const size_t wtap = (size_t)nci8 * a.nbtot * 64;
+    const size_t wq = (size_t)a.nbtot * 64;
+    const int stride_w = a.Co, stride_h = a.OW * a.Co;
+
+    f32x16 acc[MB][NB];
+    MSNET_LDS_BARRIER();                               // A_0
+    MSNET_LDS_BARRIER();                               // B_0
+    for (int it = 0; it < nitems; ++it) {
+        int g, n, od0, oh0, ow0, chunk;
+        decode(it, g, n, od0, oh0, ow0, chunk);
+        const int nb0 = (g * WN + wn) * NB;
+        if (chunk == 0) {
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+        }
+        const f32x4* wbase = a.wpk + ((size_t)(chunk * NQ) * a.nbtot + nb0) * 64 + lane;
+
+        constexpr int S = 27 * NQ;
+        f32x4 av[2][MB], bv[3][NB];
+        auto a_load = [&](f32x4 (&dst)[MB], int st) {
+            const int tap = st / NQ, q = st % NQ;
+            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+            const int toff = ((kd * IH + kh) * IW + kw) * PS + q * 8;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) dst[i] = *reinterpret_cast<const f32x4*>(lds + abase[i] + toff);
+        };
+        auto b_load = [&](f32x4 (&dst)[NB], int st) {
+            const int tap = st / NQ, q = st % NQ;
+            load_b<NB>(dst, wbase + tap * wtap + q * wq);
+        };
+        b_load(bv[0], 0);
+        if (S > 1) b_load(bv[1], 1);
+        a_load(av[0], 0);
+#pragma unroll
+        for (int st = 0; st < S; ++st) {
+            if (st + 2 < S) b_load(bv[(st + 2) % 3], st + 2);
+            if (st + 1 < S) a_load(av[(st + 1) & 1], st + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        acc[i][j] = mfma32(av[st & 1][i][t], bv[st % 3][j][t], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
+        const bool more = it + 1 < nitems;
+        if (more) MSNET_LDS_BARRIER();                 // A_{it+1}: LDS may be overwritten now
+        if (chunk == nchunks - 1) {
+            const bool full_hw = (oh0 + TH <= a.OH) && (ow0 + TW <= a.OW);
+#pragma unroll
+            for (int i = 0; i < MB; ++i) {
+                const int mb = wm * MB + i;
+                const int bw = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
+                const int od = od0 + bd;
+                if (od >= a.OD) continue;
+                const int ohb = oh0 + bh * BH, owb = ow0 + bw * BW + 4 * hh;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const int co = (nb0 + j) * 32 + r;
+                    const float sc = a.scale ? a.scale[co] : 1.f;
+                    const float sh = a.shift ? a.shift[co] : 0.f;
+                    const size_t base = ((((size_t)n * a.OD + od) * a.OH + ohb) * a.OW + owb) * a.Co + co;
+                    epilogue_block<BW>(acc[i][j], sc, sh, a.res, a.y, base, stride_h, stride_w, a.relu, full_hw,
+                                       [&](int lh, int lw) { return ohb + lh < a.OH && owb + lw < a.OW; });
+                }
+            }
+        }
+        if (more) MSNET_LDS_BARRIER();                 // B_{it+1}
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Transposed conv, kernel 3, stride 2, pad 1, output_padding 1 (out = 2 x in), as 8 output-parity
 // classes sharing one LDS tile.  o = 2i - 1 + k per dim: an even output 2j takes only (k=1, i=j); an odd
@@ -393,6 +585,22 @@ static int launch_conv(const char* name, ConvArgs a, hipStream_t s) {
     return check_launch(name);
 }
 
+template <int CC, int STRIDE, int TD, int TH, int TW, int BW, int WM, int WN, int MB, int NB>
+static int launch_conv_ws(const char* name, ConvArgs a, hipStream_t s) {
+    a.ntd = cdiv(a.OD, TD); a.nth = cdiv(a.OH, TH); a.ntw = cdiv(a.OW, TW);
+    a.ngroups = a.Co / (32 * WN * NB);
+    a.nbtot = a.Co / 32;
+    const size_t ntiles = (size_t)a.N * a.ntd * a.nth * a.ntw * a.ngroups;
+    if (ntiles == 0 || ntiles > 0x7fffffffu) return fail("%s: bad tile count %zu", name, ntiles);
+    const size_t nblk = ntiles < (size_t)num_cus() ? ntiles : (size_t)num_cus();   // persistent: one workgroup per CU
+    const double vox = (double)a.N * a.OD * a.OH * a.OW;
+    LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
+                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
+    hipLaunchKernelGGL((conv3d_k3_mfma_ws<CC, STRIDE, TD, TH, TW, BW, WM, WN, MB, NB>), dim3((unsigned)nblk),
+                       dim3(512), 0, s, a);
+    return check_launch(name);
+}
+
 template <int CI, int TD, int TH, int TW, int BW, int WM, int WN, int MB, int NB>
 static int launch_deconv(const char* name, ConvArgs a, hipStream_t s) {
     a.ntd = cdiv(a.D, TD); a.nth = cdiv(a.H, TH); a.ntw = cdiv(a.W, TW);
@@ -442,11 +650,11 @@ extern "C" int msnet_conv3d_k3(const float* x, const float* wpk, const float* sc
         }
         if (Ci % 32 == 0) {
             if (b16) {
-                if (two) return launch_conv<32, 1, 2, 8, 16, 16, 4, 1, 2, 2>("conv3d_s1", a, s);
-                return launch_conv<32, 1, 2, 8, 16, 16, 4, 1, 2, 1>("conv3d_s1", a, s);
+                if (two) return launch_conv_ws<32, 1, 2, 8, 16, 16, 4, 1, 2, 2>("conv3d_s1", a, s);
+                return launch_conv_ws<32, 1, 2, 8, 16, 16, 4, 1, 2, 1>("conv3d_s1", a, s);
             }
-            if (two) return launch_conv<32, 1, 2, 4, 32, 32, 4, 1, 2, 2>("conv3d_s1", a, s);
-            return launch_conv<32, 1, 2, 4, 32, 32, 4, 1, 2, 1>("conv3d_s1", a, s);
+            if (two) return launch_conv_ws<32, 1, 2, 4, 32, 32, 4, 1, 2, 2>("conv3d_s1", a, s);
+            return launch_conv_ws<32, 1, 2, 4, 32, 32, 4, 1, 2, 1>("conv3d_s1", a, s);
         }
         if (two) return launch_conv<16, 1, 2, 8, 16, 16, 4, 1, 2, 2>("conv3d_s1", a, s);
         return launch_conv<16, 1, 2, 8, 16, 16, 4, 1, 2, 1>("conv3d_s1", a, s);
