@@ -17,6 +17,7 @@ SOURCES = [
     ("api.cpp", []),
     ("pack.hip", []),
     ("conv3d.hip", []),
+    ("conv3d_f16s.hip", []),
     ("tail.hip", []),
     ("volume.hip", ["-ffp-contract=off"]),
 ]
@@ -42,7 +43,7 @@ def build(force=False, verbose=True):
     hipcc = _hipcc()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "msnet_hip.h"),
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(HERE, "..", "include", "msnet_hip.h"),
                os.path.abspath(__file__)]
     objs = []
     procs = []

@@ -10,9 +10,9 @@
 // Implicit GEMM:  out[pos][co] = sum_{tap, ci} in[pos (+) tap][ci] * w[co][ci][tap]
 //   M = 32 output voxels (an "M-block": BH x BW voxels of one depth slice), N = 32 output channels,
 //   K = 27 taps x Ci, walked 8 input channels at a time.
-// A workgroup (4 waves, one per SIMD, 256 threads) stages the input tile + halo for one chunk of CC
-// input channels in LDS once and re-reads it for all 27 taps and all output channels; the B operand
-// (weights, pre-packed on the device into MFMA lane order by pack.hip) streams from L2 one tap ahead.
+// A workgroup stages the input tile + halo for one chunk of CC input channels in LDS once and re-reads it for
+// all 27 taps and all output channels; the B operand (weights, pre-packed on the device into MFMA lane order
+// by pack.hip) streams from L2 two steps ahead of the MFMAs.
 //
 // MFMA operand maps (cdna_hip_programming.md section 3): for v_mfma_f32_32x32x2_f32 lane l holds
 // A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; D[i][j] sits in lane (j | 32*((i>>2)&1)),
@@ -20,252 +20,14 @@
 // ds_read_b128 / global_load_dwordx4 per lane feeds four consecutive MFMAs: lane half h reads
 // channels 8q+4h .. 8q+4h+3 and MFMA t consumes channel 8q+4h+t from each half (the weights are
 // packed with the same permutation, so the sum over K is unchanged).
-#include "common.h"
+#include "conv_common.h"
 
 namespace msnet {
-
-static int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        else n = 256;
-    }
-    return n;
-}
-
-struct ConvArgs {
-    const float* x; const f32x4* wpk; const float* scale; const float* shift; const float* res; float* y;
-    int N, D, H, W;        // input spatial dims
-    int OD, OH, OW;        // output spatial dims
-    int Ci, Co;
-    int relu;
-    int ntd, nth, ntw;     // tiles per dim (conv: over output dims; deconv: over input dims)
-    int ngroups;           // Co / (32 * WN * NB)
-    int nbtot;             // Co / 32
-};
-
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// Stage NPOS voxels x CC channels (global NDHWC, channel offset c0 of Ci) into LDS [pos][CC+4].
-// Voxels outside the input are the convolution's zero padding.
-template <int CC, int ID, int IH, int IW>
-__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ x, int n, int D, int H,
-                                           int W, int Ci, int c0, int id0, int ih0, int iw0, int tid) {
-    constexpr int PS = CC + 4;
-    constexpr int V = CC / 4;                 // float4 per voxel
-    constexpr int NSLOT = ID * IH * IW * V;
-    constexpr int U = 8;                      // loads in flight per thread
-    for (int base = 0; base < NSLOT; base += 256 * U) {
-        f32x4 v[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int slot = base + u * 256 + tid;
-            const int pos = slot / V, c4 = slot % V;
-            const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
-            const int gd = id0 + id, gh = ih0 + ih, gw = iw0 + iw;
-            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (slot < NSLOT && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H &&
-                (unsigned)gw < (unsigned)W) {
-                const size_t vox = (((size_t)n * D + gd) * H + gh) * W + gw;
-                v[u] = *reinterpret_cast<const f32x4*>(x + vox * Ci + c0 + c4 * 4);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int slot = base + u * 256 + tid;
-            if (slot < NSLOT) {
-                const int pos = slot / V, c4 = slot % V;
-                *reinterpret_cast<f32x4*>(lds + pos * PS + c4 * 4) = v[u];
-            }
-        }
-    }
-}
-
-template <int NB>
-__device__ __forceinline__ void load_b(f32x4 (&b)[NB], const f32x4* __restrict__ p) {
-#pragma unroll
-    for (int j = 0; j < NB; ++j) b[j] = p[j * 64];
-}
-
-// Epilogue of one 32x32 accumulator block: y = act(acc*scale + shift (+ residual)).  For accumulator register e
-// the 32 lanes of a half hold the 32 channels of ONE voxel (two full 128-byte lines per store instruction).
-// Voxel of (e, half hh): local row = c_e + 4*hh with c_e = (e&3) + 8*(e>>2); because c_e % BW is in 0..3 (+8k) the
-// 4*hh never carries into the h index, so the offset splits into a lane-dependent base (folded into `base` by the
-// caller) plus compile-time multiples of two uniform strides.  FULL tiles take the branch-free path: all residual
-// loads are issued before the first use (the naive per-element form serialised 16 dependent HBM round trips per
-// block and ran the transposed convs at 30 TFLOP/s, profiles/r01b).
-template <int BW, class Valid>
-__device__ __forceinline__ void epilogue_block(const f32x16& acc, float sc, float sh, const float* __restrict__ res,
-                                               float* __restrict__ y, size_t base, int stride_h, int stride_w, int relu,
-                                               bool full, Valid valid) {
-    if (full) {
-        float rv[16];
-        if (res) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int c = (e & 3) + 8 * (e >> 2);
-                rv[e] = res[base + (size_t)((c / BW) * stride_h + (c % BW) * stride_w)];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) rv[e] = 0.f;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int c = (e & 3) + 8 * (e >> 2);
-            float v = acc[e] * sc + sh + rv[e];
-            if (relu) v = fmaxf(v, 0.f);
-            y[base + (size_t)((c / BW) * stride_h + (c % BW) * stride_w)] = v;
-        }
-    } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int c = (e & 3) + 8 * (e >> 2);
-            if (valid(c / BW, c % BW)) {
-                const size_t idx = base + (size_t)((c / BW) * stride_h + (c % BW) * stride_w);
-                float v = acc[e] * sc + sh;
-                if (res) v += res[idx];
-                if (relu) v = fmaxf(v, 0.f);
-                y[idx] = v;
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Forward conv, kernel 3, pad 1, stride STRIDE.
-//   tile: TD x TH x TW output voxels = WM*MB M-blocks of (32/BW) x BW voxels; WN*NB N-blocks.
-// ---------------------------------------------------------------------------------------------
-template <int CC, int STRIDE, int TD, int TH, int TW, int BW, int WM, int WN, int MB, int NB>
-__global__ __launch_bounds__(256, 1) void conv3d_k3_mfma(ConvArgs a) {
-    constexpr int BH = 32 / BW;
-    constexpr int ID = (TD - 1) * STRIDE + 3, IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
-    constexpr int PS = CC + 4;
-    constexpr int NQ = CC / 8;
-    constexpr int MW = TW / BW, MH = TH / BH;
-    static_assert(TD * MH * MW == WM * MB, "M-block count mismatch");
-    static_assert(WM * WN == 4, "4 waves per workgroup");
-    __shared__ __attribute__((aligned(16))) float lds[ID * IH * IW * PS];
-
-    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int g = bid % a.ngroups; bid /= a.ngroups;
-    const int tw = bid % a.ntw; bid /= a.ntw;
-    const int th = bid % a.nth; bid /= a.nth;
-    const int td = bid % a.ntd;
-    const int n = bid / a.ntd;
-    const int od0 = td * TD, oh0 = th * TH, ow0 = tw * TW;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave % WM, wn = wave / WM;
-    const int r = lane & 31, hh = lane >> 5;
-
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-    int abase[MB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i) {
-        const int mb = wm * MB + i;
-        const int bw = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
-        const int lh = bh * BH + r / BW, lw = bw * BW + r % BW;
-        abase[i] = ((bd * STRIDE * IH + lh * STRIDE) * IW + lw * STRIDE) * PS + 4 * hh;
-    }
-    const int nb0 = (g * WN + wn) * NB;
-    const int nci8 = a.Ci >> 3;
-    const int nchunks = a.Ci / CC;
-
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        __syncthreads();
-        stage_tile<CC, ID, IH, IW>(lds, a.x, n, a.D, a.H, a.W, a.Ci, chunk * CC, od0 * STRIDE - 1,
-                                   oh0 * STRIDE - 1, ow0 * STRIDE - 1, tid);
-        __syncthreads();
-
-        // weights for (tap, q): wpk[((tap*nci8 + chunk*NQ + q) * nbtot + nb) * 64 + lane]
-        const f32x4* wbase = a.wpk + ((size_t)(chunk * NQ) * a.nbtot + nb0) * 64 + lane;
-        const size_t wtap = (size_t)nci8 * a.nbtot * 64;
-        const size_t wq = (size_t)a.nbtot * 64;
-
-        // Software pipeline over the S = 27*NQ (tap, q) steps: the A fragments (LDS) run one step ahead, the B
-        // fragments (L2) two steps ahead, in statically indexed register rings; sched_barrier pins "issue the
-        // prefetches, then the MFMA block" -- left alone, hipcc sinks every load to just before its first use and
-        // exposes the full L2 latency once per step (profiles/r01a: 78 TFLOP/s).
-        constexpr int S = 27 * NQ;
-        f32x4 av[2][MB], bv[3][NB];
-        auto a_load = [&](f32x4 (&dst)[MB], int st) {
-            const int tap = st / NQ, q = st % NQ;
-            const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-            const int toff = ((kd * IH + kh) * IW + kw) * PS + q * 8;
-#pragma unroll
-            for (int i = 0; i < MB; ++i) dst[i] = *reinterpret_cast<const f32x4*>(lds + abase[i] + toff);
-        };
-        auto b_load = [&](f32x4 (&dst)[NB], int st) {
-            const int tap = st / NQ, q = st % NQ;
-            load_b<NB>(dst, wbase + tap * wtap + q * wq);
-        };
-        b_load(bv[0], 0);
-        if (S > 1) b_load(bv[1], 1);
-        a_load(av[0], 0);
-#pragma unroll
-        for (int st = 0; st < S; ++st) {
-            if (st + 2 < S) b_load(bv[(st + 2) % 3], st + 2);
-            if (st + 1 < S) a_load(av[(st + 1) & 1], st + 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int i = 0; i < MB; ++i)
-#pragma unroll
-                    for (int j = 0; j < NB; ++j)
-                        acc[i][j] = mfma32(av[st & 1][i][t], bv[st % 3][j][t], acc[i][j]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-    // Epilogue: BN affine (+ skip) (+ ReLU).
-    const bool full_hw = (oh0 + TH <= a.OH) && (ow0 + TW <= a.OW);
-    const int stride_w = a.Co, stride_h = a.OW * a.Co;
-#pragma unroll
-    for (int i = 0; i < MB; ++i) {
-        const int mb = wm * MB + i;
-        const int bw = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
-        const int od = od0 + bd;
-        if (od >= a.OD) continue;
-        const int ohb = oh0 + bh * BH, owb = ow0 + bw * BW + 4 * hh;      // voxel of (c_e = 0, half hh)
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            const int co = (nb0 + j) * 32 + r;
-            const float sc = a.scale ? a.scale[co] : 1.f;
-            const float sh = a.shift ? a.shift[co] : 0.f;
-            const size_t base = ((((size_t)n * a.OD + od) * a.OH + ohb) * a.OW + owb) * a.Co + co;
-            epilogue_block<BW>(acc[i][j], sc, sh, a.res, a.y, base, stride_h, stride_w, a.relu, full_hw,
-                               [&](int lh, int lw) { return ohb + lh < a.OH && owb + lw < a.OW; });
-        }
-    }
-}
-
-// LDS-only workgroup barrier: orders LDS traffic across the s_barrier without draining the vector-memory
-// counter (a plain __syncthreads() may add s_waitcnt vmcnt(0), which would stall the compute waves on their
-// in-flight weight loads and the loader waves on nothing useful).
-#define MSNET_LDS_BARRIER()                                              \
-    do {                                                                 \
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  \
-        __builtin_amdgcn_s_barrier();                                    \
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");  \
-    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // Wave-specialised, persistent form of the forward conv (the one the big layers use).
 //   8 waves per workgroup, two per SIMD: waves 0-3 ("compute") run the software-pipelined MFMA loop and the
-//   epilogue exactly as conv3d_k3_mfma does; waves 4-7 ("loaders") fetch the NEXT work item's input tile from
+//   epilogue; waves 4-7 ("loaders") fetch the NEXT work item's input tile from
 //   HBM/L2 into registers while the MFMAs run, then drop it into LDS between two barriers:
 //        loader :  issue(k) ... wait        |A_k| write LDS |B_k| issue(k+1) ...
 //        compute:  MFMA(k-1)                |A_k| epilogue(k-1) |B_k| MFMA(k) ...
@@ -515,8 +277,11 @@ __device__ __forceinline__ void deconv_class(const float* lds, const int (&abase
     }
 }
 
+// 8 waves per workgroup, two per SIMD: waves 0-3 and waves 4-7 both cover all WM x WN blocks of the tile but
+// take complementary halves of the 8 parity classes (13 vs 14 of the 27 taps), so one set's epilogue (residual
+// reads + strided stores, memory-bound) runs under the other set's MFMAs.
 template <int CI, int TD, int TH, int TW, int BW, int WM, int WN, int MB, int NB>
-__global__ __launch_bounds__(256, 1) void deconv3d_k3s2_mfma(ConvArgs a) {
+__global__ __launch_bounds__(512, 2) void deconv3d_k3s2_mfma(ConvArgs a) {
     constexpr int BH = 32 / BW;
     constexpr int ID = TD + 1, IH = TH + 1, IW = TW + 1;
     constexpr int PS = CI + 4;
@@ -534,11 +299,13 @@ __global__ __launch_bounds__(256, 1) void deconv3d_k3s2_mfma(ConvArgs a) {
     const int n = bid / a.ntd;
     const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cset = wave8 >> 2, wave = wave8 & 3;
     const int wm = wave % WM, wn = wave / WM;
     const int r = lane & 31, hh = lane >> 5;
 
-    stage_tile<CI, ID, IH, IW>(lds, a.x, n, a.D, a.H, a.W, a.Ci, 0, d0, h0, w0, tid);
+    stage_tile<CI, ID, IH, IW, 512>(lds, a.x, n, a.D, a.H, a.W, a.Ci, 0, d0, h0, w0, tid);
     __syncthreads();
 
     int abase[MB];
@@ -556,35 +323,23 @@ __global__ __launch_bounds__(256, 1) void deconv3d_k3s2_mfma(ConvArgs a) {
 
 #define MSNET_DECONV_CLASS(PD, PH, PW) \
     deconv_class<CI, IH, IW, BW, MH, MW, MB, NB, PD, PH, PW>(lds, abase, wbase, wtap, wq, a, n, d0, h0, w0, wm, nb0, r, hh)
-    MSNET_DECONV_CLASS(1, 1, 1);   // heaviest class first
-    MSNET_DECONV_CLASS(1, 1, 0);
-    MSNET_DECONV_CLASS(1, 0, 1);
-    MSNET_DECONV_CLASS(0, 1, 1);
-    MSNET_DECONV_CLASS(1, 0, 0);
-    MSNET_DECONV_CLASS(0, 1, 0);
-    MSNET_DECONV_CLASS(0, 0, 1);
-    MSNET_DECONV_CLASS(0, 0, 0);
+    if (cset == 0) {                    // 8 + 2 + 2 + 1 = 13 taps
+        MSNET_DECONV_CLASS(1, 1, 1);
+        MSNET_DECONV_CLASS(0, 0, 1);
+        MSNET_DECONV_CLASS(0, 1, 0);
+        MSNET_DECONV_CLASS(0, 0, 0);
+    } else {                            // 4 + 4 + 4 + 2 = 14 taps
+        MSNET_DECONV_CLASS(1, 1, 0);
+        MSNET_DECONV_CLASS(1, 0, 1);
+        MSNET_DECONV_CLASS(0, 1, 1);
+        MSNET_DECONV_CLASS(1, 0, 0);
+    }
 #undef MSNET_DECONV_CLASS
 }
 
 // ---------------------------------------------------------------------------------------------
 // Host dispatch
 // ---------------------------------------------------------------------------------------------
-template <int CC, int STRIDE, int TD, int TH, int TW, int BW, int WM, int WN, int MB, int NB>
-static int launch_conv(const char* name, ConvArgs a, hipStream_t s) {
-    a.ntd = cdiv(a.OD, TD); a.nth = cdiv(a.OH, TH); a.ntw = cdiv(a.OW, TW);
-    a.ngroups = a.Co / (32 * WN * NB);
-    a.nbtot = a.Co / 32;
-    const size_t nblk = (size_t)a.N * a.ntd * a.nth * a.ntw * a.ngroups;
-    if (nblk == 0 || nblk > 0x7fffffffu) return fail("%s: bad grid %zu", name, nblk);
-    const double vox = (double)a.N * a.OD * a.OH * a.OW;
-    LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
-                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((conv3d_k3_mfma<CC, STRIDE, TD, TH, TW, BW, WM, WN, MB, NB>), dim3((unsigned)nblk),
-                       dim3(256), 0, s, a);
-    return check_launch(name);
-}
-
 template <int CC, int STRIDE, int TD, int TH, int TW, int BW, int WM, int WN, int MB, int NB>
 static int launch_conv_ws(const char* name, ConvArgs a, hipStream_t s) {
     a.ntd = cdiv(a.OD, TD); a.nth = cdiv(a.OH, TH); a.ntw = cdiv(a.OW, TW);
@@ -611,7 +366,7 @@ static int launch_deconv(const char* name, ConvArgs a, hipStream_t s) {
     const double ivox = (double)a.N * a.D * a.H * a.W;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * ivox,
                    4.0 * (ivox * a.Ci + 8.0 * ivox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((deconv3d_k3s2_mfma<CI, TD, TH, TW, BW, WM, WN, MB, NB>), dim3((unsigned)nblk), dim3(256),
+    hipLaunchKernelGGL((deconv3d_k3s2_mfma<CI, TD, TH, TW, BW, WM, WN, MB, NB>), dim3((unsigned)nblk), dim3(512),
                        0, s, a);
     return check_launch(name);
 }
@@ -645,8 +400,8 @@ extern "C" int msnet_conv3d_k3(const float* x, const float* wpk, const float* sc
     if (stride == 1) {
         if (Ci == 8) {
             //            CC S TD TH TW  BW WM WN MB NB
-            if (two) return launch_conv<8, 1, 2, 8, 32, 32, 4, 1, 4, 2>("conv3d_s1_c8", a, s);
-            return launch_conv<8, 1, 4, 8, 32, 32, 4, 1, 8, 1>("conv3d_s1_c8", a, s);
+            if (two) return launch_conv_ws<8, 1, 2, 4, 32, 32, 4, 1, 2, 2>("conv3d_s1_c8", a, s);
+            return launch_conv_ws<8, 1, 2, 8, 32, 32, 4, 1, 4, 1>("conv3d_s1_c8", a, s);
         }
         if (Ci % 32 == 0) {
             if (b16) {
@@ -656,14 +411,14 @@ extern "C" int msnet_conv3d_k3(const float* x, const float* wpk, const float* sc
             if (two) return launch_conv_ws<32, 1, 2, 4, 32, 32, 4, 1, 2, 2>("conv3d_s1", a, s);
             return launch_conv_ws<32, 1, 2, 4, 32, 32, 4, 1, 2, 1>("conv3d_s1", a, s);
         }
-        if (two) return launch_conv<16, 1, 2, 8, 16, 16, 4, 1, 2, 2>("conv3d_s1", a, s);
-        return launch_conv<16, 1, 2, 8, 16, 16, 4, 1, 2, 1>("conv3d_s1", a, s);
+        if (two) return launch_conv_ws<16, 1, 2, 8, 16, 16, 4, 1, 2, 2>("conv3d_s1", a, s);
+        return launch_conv_ws<16, 1, 2, 8, 16, 16, 4, 1, 2, 1>("conv3d_s1", a, s);
     }
     // stride 2: the input halo tile is (2T+1)^3 voxels, so stage 16 channels at a time and keep the tile at
     // 2x4x16 outputs (4 M-blocks); with Co >= 64 the four waves split 2 (M) x 2 (N).
     if (Ci % 16 != 0) return fail("msnet_conv3d_k3: stride 2 needs Ci %% 16 == 0 (got %d)", Ci);
-    if (two) return launch_conv<16, 2, 2, 4, 16, 16, 2, 2, 2, 1>("conv3d_s2", a, s);
-    return launch_conv<16, 2, 2, 4, 16, 16, 4, 1, 1, 1>("conv3d_s2", a, s);
+    if (two) return launch_conv_ws<16, 2, 2, 4, 16, 16, 2, 2, 2, 1>("conv3d_s2", a, s);
+    return launch_conv_ws<16, 2, 2, 4, 16, 16, 4, 1, 1, 1>("conv3d_s2", a, s);
 }
 
 extern "C" int msnet_deconv3d_k3s2(const float* x, const float* wpk, const float* scale, const float* shift,

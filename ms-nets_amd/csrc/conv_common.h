@@ -1,0 +1,130 @@
+// Shared device helpers of the 3x3x3 conv kernels (conv3d.hip: exact fp32 MFMA; conv3d_f16s.hip: split-fp16 MFMA).
+#pragma once
+#include "common.h"
+
+
+namespace msnet {
+
+static inline int num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+        else n = 256;
+    }
+    return n;
+}
+
+struct ConvArgs {
+    const float* x; const f32x4* wpk; const float* scale; const float* shift; const float* res; float* y;
+    int N, D, H, W;        // input spatial dims
+    int OD, OH, OW;        // output spatial dims
+    int Ci, Co;
+    int relu;
+    int ntd, nth, ntw;     // tiles per dim (conv: over output dims; deconv: over input dims)
+    int ngroups;           // Co / (32 * WN * NB)
+    int nbtot;             // Co / 32
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// Stage NPOS voxels x CC channels (global NDHWC, channel offset c0 of Ci) into LDS [pos][CC+4].
+// Voxels outside the input are the convolution's zero padding.
+template <int CC, int ID, int IH, int IW, int NT = 256>
+__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ x, int n, int D, int H,
+                                           int W, int Ci, int c0, int id0, int ih0, int iw0, int tid) {
+    constexpr int PS = CC + 4;
+    constexpr int V = CC / 4;                 // float4 per voxel
+    constexpr int NSLOT = ID * IH * IW * V;
+    constexpr int U = 8;                      // loads in flight per thread
+    for (int base = 0; base < NSLOT; base += NT * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int slot = base + u * NT + tid;
+            const int pos = slot / V, c4 = slot % V;
+            const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
+            const int gd = id0 + id, gh = ih0 + ih, gw = iw0 + iw;
+            v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (slot < NSLOT && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H &&
+                (unsigned)gw < (unsigned)W) {
+                const size_t vox = (((size_t)n * D + gd) * H + gh) * W + gw;
+                v[u] = *reinterpret_cast<const f32x4*>(x + vox * Ci + c0 + c4 * 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int slot = base + u * NT + tid;
+            if (slot < NSLOT) {
+                const int pos = slot / V, c4 = slot % V;
+                *reinterpret_cast<f32x4*>(lds + pos * PS + c4 * 4) = v[u];
+            }
+        }
+    }
+}
+
+template <int NB>
+__device__ __forceinline__ void load_b(f32x4 (&b)[NB], const f32x4* __restrict__ p) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) b[j] = p[j * 64];
+}
+
+// Epilogue of one 32x32 accumulator block: y = act(acc*scale + shift (+ residual)).  For accumulator register e
+// the 32 lanes of a half hold the 32 channels of ONE voxel (two full 128-byte lines per store instruction).
+// Voxel of (e, half hh): local row = c_e + 4*hh with c_e = (e&3) + 8*(e>>2); because c_e % BW is in 0..3 (+8k) the
+// 4*hh never carries into the h index, so the offset splits into a lane-dependent base (folded into `base` by the
+// caller) plus compile-time multiples of two uniform strides.  FULL tiles take the branch-free path: all residual
+// loads are issued before the first use (the naive per-element form serialised 16 dependent HBM round trips per
+// block and ran the transposed convs at 30 TFLOP/s, profiles/r01b).
+template <int BW, class Valid>
+__device__ __forceinline__ void epilogue_block(const f32x16& acc, float sc, float sh, const float* __restrict__ res,
+                                               float* __restrict__ y, size_t base, int stride_h, int stride_w, int relu,
+                                               bool full, Valid valid) {
+    if (full) {
+        float rv[16];
+        if (res) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int c = (e & 3) + 8 * (e >> 2);
+                rv[e] = res[base + (size_t)((c / BW) * stride_h + (c % BW) * stride_w)];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = (e & 3) + 8 * (e >> 2);
+            float v = acc[e] * sc + sh + rv[e];
+            if (relu) v = fmaxf(v, 0.f);
+            y[base + (size_t)((c / BW) * stride_h + (c % BW) * stride_w)] = v;
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = (e & 3) + 8 * (e >> 2);
+            if (valid(c / BW, c % BW)) {
+                const size_t idx = base + (size_t)((c / BW) * stride_h + (c % BW) * stride_w);
+                float v = acc[e] * sc + sh;
+                if (res) v += res[idx];
+                if (relu) v = fmaxf(v, 0.f);
+                y[idx] = v;
+            }
+        }
+    }
+}
+
+// LDS-only workgroup barrier: orders LDS traffic across the s_barrier without draining the vector-memory
+// counter (a plain __syncthreads() may add s_waitcnt vmcnt(0), which would stall the compute waves on their
+// in-flight weight loads and the loader waves on nothing useful).
+#define MSNET_LDS_BARRIER()                                              \
+    do {                                                                 \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");  \
+        __builtin_amdgcn_s_barrier();                                    \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");  \
+    } while (0)
+
+}  // namespace msnet

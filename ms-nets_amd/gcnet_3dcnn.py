@@ -71,7 +71,7 @@ class GCNet_CostVolumeAggre(nn.Module):
 
     # ---- device constants ------------------------------------------------------------------------
     def _plans(self):
-        key = hipops.state_key(self)
+        key = hipops.state_key(self) + (hipops.get_default_precision(),)
         if self._plan is None or key != self._plan_key:
             P = hipops.ConvBNPlan
             plan = {"conv3dbn_1": P(*self.conv3dbn_1), "conv3dbn_2": P(*self.conv3dbn_2)}
@@ -104,7 +104,8 @@ class GCNet_CostVolumeAggre(nn.Module):
 
         def conv(x, name, stride=1, residual=None):
             p = pl[name]
-            return hipops.conv3d_k3(x, p.wpk, p.scale, p.shift, p.co, stride=stride, relu=True, residual=residual)
+            return hipops.conv3d_k3(x, p.wpk, p.scale, p.shift, p.co, stride=stride, relu=True, residual=residual,
+                                     f16s=p.f16s)
 
         def block(x, name, stride):
             x = conv(x, name + ".convbn_3d_1", stride)

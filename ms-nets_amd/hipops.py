@@ -24,20 +24,42 @@ def ndhwc_to_ncdhw(x):
     return y
 
 
-def pack_conv_weight(w, transposed=False):
-    """nn.Conv3d.weight [Co,Ci,3,3,3] (or ConvTranspose3d.weight [Ci,Co,3,3,3]) -> MFMA-ordered buffer."""
+def pack_conv_weight(w, transposed=False, f16s=False):
+    """nn.Conv3d.weight [Co,Ci,3,3,3] (or ConvTranspose3d.weight [Ci,Co,3,3,3]) -> MFMA-ordered buffer
+    (fp32 lane order, or the split-fp16 hi/lo image when f16s)."""
     w = require_gpu_f32(w, "weight")
     if tuple(w.shape[2:]) != (3, 3, 3):
         raise ValueError("only 3x3x3 kernels are built (got %s)" % (tuple(w.shape),))
     ci, co = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     lib = _lib.load()
     out = torch.empty(lib.msnet_packed_weight_floats(ci, co), device=w.device, dtype=torch.float32)
+    if f16s:
+        check(lib.msnet_pack_conv_weight_f16s(ptr(w), ptr(out), ci, co, int(transposed), stream_ptr()),
+              "msnet_pack_conv_weight_f16s")
+        return out
     fn = lib.msnet_pack_deconv_weight if transposed else lib.msnet_pack_conv_weight
     check(fn(ptr(w), ptr(out), ci, co, stream_ptr()), "msnet_pack_weight")
     return out
 
 
-def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None):
+PRECISIONS = ("fp32", "split-fp16")
+_default_precision = "split-fp16"
+
+
+def set_default_precision(p):
+    """'fp32': exact fp32-input MFMA everywhere.  'split-fp16': layers that have a split-fp16 kernel use it
+    (3 fp16 MFMAs per product, 22-bit operands), the rest stay on the fp32 MFMA."""
+    global _default_precision
+    if p not in PRECISIONS:
+        raise ValueError("precision must be one of %s" % (PRECISIONS,))
+    _default_precision = p
+
+
+def get_default_precision():
+    return _default_precision
+
+
+def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16s=False):
     x = require_gpu_f32(x, "x")
     n, d, h, w, ci = x.shape
     od, oh, ow = (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1
@@ -46,8 +68,9 @@ def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None):
         residual = require_gpu_f32(residual, "residual")
         if residual.shape != y.shape:
             raise ValueError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
-    check(_lib.load().msnet_conv3d_k3(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(residual), ptr(y), n, d, h, w, ci,
-                                      co, stride, int(relu), stream_ptr()), "msnet_conv3d_k3")
+    fn = _lib.load().msnet_conv3d_k3_f16s if f16s else _lib.load().msnet_conv3d_k3
+    check(fn(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(residual), ptr(y), n, d, h, w, ci, co, stride, int(relu),
+             stream_ptr()), "msnet_conv3d_k3_f16s" if f16s else "msnet_conv3d_k3")
     return y
 
 
@@ -122,10 +145,15 @@ class ConvBNPlan:
     """Device-side constants of one conv(+BN) layer: MFMA-packed weight and the eval-mode BN affine
     y = x*scale + shift with scale = gamma/sqrt(var+eps), shift = beta - mean*scale."""
 
-    def __init__(self, conv, bn=None, transposed=False):
+    def __init__(self, conv, bn=None, transposed=False, precision=None):
         w = conv.weight.detach()
         self.co = w.shape[1] if transposed else w.shape[0]
-        self.wpk = pack_conv_weight(w, transposed)
+        ci = w.shape[0] if transposed else w.shape[1]
+        stride = conv.stride[0]
+        precision = precision or _default_precision
+        self.f16s = bool(precision == "split-fp16" and not transposed and
+                         _lib.load().msnet_conv3d_k3_f16s_supported(ci, self.co, stride))
+        self.wpk = pack_conv_weight(w, transposed, f16s=self.f16s)
         if bn is not None:
             inv = 1.0 / torch.sqrt(bn.running_var.detach().float() + bn.eps)
             self.scale = (bn.weight.detach().float() * inv).contiguous()

@@ -62,7 +62,7 @@ class PSMNet_CostVolumeAggre(nn.Module):
         self._plan_key = None
 
     def _plans(self):
-        key = hipops.state_key(self)
+        key = hipops.state_key(self) + (hipops.get_default_precision(),)
         if self._plan is None or key != self._plan_key:
             P = hipops.ConvBNPlan
             pl = {"dres0.0": P(*self.dres0[0]), "dres0.2": P(*self.dres0[2]),
@@ -92,7 +92,8 @@ class PSMNet_CostVolumeAggre(nn.Module):
 
         def conv(x, name, stride=1, relu=True, residual=None):
             p = pl[name]
-            return hipops.conv3d_k3(x, p.wpk, p.scale, p.shift, p.co, stride=stride, relu=relu, residual=residual)
+            return hipops.conv3d_k3(x, p.wpk, p.scale, p.shift, p.co, stride=stride, relu=relu, residual=residual,
+                                     f16s=p.f16s)
 
         def deconv(x, name, relu, residual):
             p = pl[name]

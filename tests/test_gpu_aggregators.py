@@ -57,6 +57,42 @@ CONV_CASES = [
 ]
 
 
+F16S_CASES = [
+    (32, 32, (1, 4, 9, 40), True, False),
+    (32, 32, (2, 3, 8, 16), True, True),
+    (32, 64, (1, 5, 6, 19), True, False),
+    (64, 64, (1, 4, 10, 24), True, True),
+    (64, 32, (1, 4, 8, 48), False, False),
+    (128, 64, (1, 3, 5, 9), True, False),
+]
+
+
+@pytest.mark.parametrize("ci,co,dims,relu,use_res", F16S_CASES)
+def test_conv3d_layer_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res):
+    """Split-fp16 MFMA path: operands carry 22 bits, so a single layer agrees with the fp64 conv to ~1e-6
+    relative (plain fp16 operands would be ~5e-4)."""
+    from msnets_amd import hipops
+    assert hiplib.msnet_conv3d_k3_f16s_supported(ci, co, 1) == 1
+    g = torch.Generator().manual_seed(ci * 31 + co)
+    n, d, h, w = dims
+    x = torch.randn((n, ci, d, h, w), generator=g) * 3
+    wt = torch.randn((co, ci, 3, 3, 3), generator=g) * (2.0 / (27 * ci)) ** 0.5
+    scale = torch.rand(co, generator=g) + 0.5
+    shift = torch.randn(co, generator=g) * 0.1
+    ref = F.conv3d(x.double(), wt.double(), None, padding=1) * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    wpk = hipops.pack_conv_weight(wt.cuda(), f16s=True)
+    y = hipops.conv3d_k3(_cl(x), wpk, scale.cuda(), shift.cuda(), co, relu=relu, residual=_cl(res) if use_res else None,
+                         f16s=True)
+    err = _rel(_nc(y).double(), ref)
+    print("split-fp16 %d->%d rel err %.2e" % (ci, co, err))
+    assert err < 5e-6
+
+
 @pytest.mark.parametrize("ci,co,stride,dims,relu,use_res", CONV_CASES)
 def test_conv3d_layer(gpu, ci, co, stride, dims, relu, use_res):
     from msnets_amd import hipops
@@ -172,9 +208,18 @@ def _our_classes():
     return GCNet_CostVolumeAggre, PSMNet_CostVolumeAggre
 
 
+@pytest.fixture(params=["split-fp16", "fp32"])
+def precision(request):
+    from msnets_amd import hipops
+    old = hipops.get_default_precision()
+    hipops.set_default_precision(request.param)
+    yield request.param
+    hipops.set_default_precision(old)
+
+
 @pytest.mark.parametrize("name", sorted(recipes.AGG_CASES))
-def test_golden_end_to_end(gpu, name):
-    """HIP module vs the reference's own output on the same seeded weights and input."""
+def test_golden_end_to_end(gpu, name, precision):
+    """HIP module vs the reference's own output on the same seeded weights and input, for both conv precisions."""
     case = recipes.AGG_CASES[name]
     gold = np.load(os.path.join(GOLD, "aggregators_%s.npz" % name))
     model = recipes.build_case(case, *_our_classes())
@@ -184,7 +229,7 @@ def test_golden_end_to_end(gpu, name):
     model = model.cuda()
     disp = model(x.cuda()).cpu()            # fused-tail path
     err = float(np.abs(disp.numpy() - gold["disp"]).max())
-    print("%s: max|disp - reference| = %.3e" % (name, err))
+    print("%s [%s]: max|disp - reference| = %.3e" % (name, precision, err))
     assert err <= DISP_TOL
     # every intermediate activation against the oracle (un-fused tail path, exercises msnet_softargmin too)
     taps_hip, taps_or = {}, {}
