@@ -47,10 +47,10 @@ def gather_disparities(local_disp, n_total):
     if local_disp.shape[0] < n_max:
         send = torch.zeros((n_max, H, W), dtype=local_disp.dtype, device=local_disp.device)
         send[:local_disp.shape[0]] = local_disp
-    recv = torch.empty((world, n_max, H, W), dtype=local_disp.dtype, device=local_disp.device)
-    dist.all_gather_into_tensor(recv, send.contiguous())
-    # recv[r, j] is sample j*world + r
-    return recv.permute(1, 0, 2, 3).reshape(world * n_max, H, W)[:n_total].contiguous()
+    recv = torch.empty((world * n_max, H, W), dtype=local_disp.dtype, device=local_disp.device)
+    dist.all_gather_into_tensor(recv, send.contiguous())      # rank-major concatenation along dim 0
+    # recv.view(world, n_max)[r, j] is sample j*world + r
+    return recv.view(world, n_max, H, W).permute(1, 0, 2, 3).reshape(world * n_max, H, W)[:n_total].contiguous()
 
 
 def barrier():

@@ -1,0 +1,69 @@
+"""CPU, world_size 2, gloo: the rank-sharding + all-gather contract of ms-nets_amd/dist.py."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+    import msnets_amd  # noqa: F401
+    from msnets_amd import dist as msdist
+    r, w, _ = msdist.init_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    mine = msdist.shard_indices(n_total, r, w)
+    H, W = 3, 5
+    local = torch.stack([torch.full((H, W), float(i)) for i in mine]) if mine else torch.zeros((0, H, W))
+    out = msdist.gather_disparities(local, n_total)
+    msdist.barrier()
+    q.put((rank, mine, out[:, 0, 0].tolist(), tuple(out.shape)))
+    torch.distributed.destroy_process_group()
+
+
+def _run(n_total):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=120) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    return sorted(res)
+
+
+def test_even_batch_round_robin_and_order():
+    res = _run(4)
+    assert res[0][1] == [0, 2] and res[1][1] == [1, 3]           # sample i -> rank i mod world
+    for _, _, vals, shape in res:
+        assert shape == (4, 3, 5) and vals == [0.0, 1.0, 2.0, 3.0]   # original order on every rank
+
+
+def test_uneven_batch_is_padded_for_the_collective():
+    res = _run(3)
+    assert res[0][1] == [0, 2] and res[1][1] == [1]
+    for _, _, vals, shape in res:
+        assert shape == (3, 3, 5) and vals == [0.0, 1.0, 2.0]
+
+
+def test_single_process_is_identity():
+    import msnets_amd  # noqa: F401
+    from msnets_amd import dist as msdist
+    x = torch.rand(2, 3, 4)
+    assert msdist.gather_disparities(x, 2) is x
+    assert msdist.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]

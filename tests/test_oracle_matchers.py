@@ -1,0 +1,141 @@
+"""CPU: known-answer and property tests of the matcher oracle (oracle/matchers_oracle.c + oracle/ms_volume.py).
+The reference's C++ cannot be built here (Boost.Python), so these pin the restatement to the semantics
+SURVEY.md section 8a/H2-H4 spells out, with tiny independent pure-Python/NumPy evaluations."""
+import numpy as np
+import pytest
+
+from oracle import ms_volume as O
+
+SENT = np.float32(2147483648.0)
+
+
+def _rand_pair(H, W, seed):
+    rng = np.random.default_rng(seed)
+    return rng.integers(0, 256, (H, W), dtype=np.uint8), rng.integers(0, 256, (H, W), dtype=np.uint8)
+
+
+def test_sentinel_is_rand_max_as_float():
+    l, r = _rand_pair(20, 30, 0)
+    c = O.census(l, r, 4, 11)
+    assert c[0, 0, 0] == SENT and c.dtype == np.float32
+
+
+def test_census_small_known_answer():
+    """Independent evaluation of the 11x11 census Hamming distance at every valid (i, j, d)."""
+    l, r = _rand_pair(16, 19, 1)
+    nd, ws, wc = 5, 11, 5
+    got = O.census(l, r, nd, ws)
+    H, W = l.shape
+    exp = np.full((H, W, nd), SENT, np.float32)
+    for i in range(H - ws):
+        for j in range(W - ws):
+            bl = l[i:i + ws, j:j + ws].astype(int) > int(l[i + wc, j + wc])
+            for d in range(min(nd, j + 1)):
+                br = r[i:i + ws, j - d:j - d + ws].astype(int) > int(r[i + wc, j - d + wc])
+                exp[i + wc, j + wc, d] = np.count_nonzero(bl != br)
+    assert np.array_equal(got, exp)
+
+
+def test_loop_bounds_are_strictly_less_than():
+    """i < H - wsize (not <=): the last window position is never evaluated."""
+    l, r = _rand_pair(14, 15, 2)
+    z = O.zsad(l, r, 2, 5)          # [nd, H, W], valid rows 2 .. H-5-1+2 = 10
+    assert np.all(z[0, 11] == SENT) and np.any(z[0, 10] != SENT)
+    s = O.sobel(l)                  # valid rows 1 .. H-3-1+1 = 11
+    assert np.all(s[12:] == 0) and np.all(s[0] == 0) and np.any(s[11] != 0)
+
+
+def test_sobel_known_answer():
+    img = np.zeros((6, 7), np.uint8)
+    img[:, 3:] = 10                                  # vertical edge
+    s = O.sobel(img)
+    assert s[1, 2] == 0 + 4 * 10 * 1.0               # [-1 0 1; -2 0 2; -1 0 1] on columns (1,2,3) -> (0,0,10)
+    assert s[1, 3] == 40.0 and s[1, 4] == 0.0 and s.dtype == np.float32
+
+
+def test_zsad_small_known_answer():
+    l, r = _rand_pair(9, 12, 3)
+    nd, ws, wc = 3, 5, 2
+    got = O.zsad(l, r, nd, ws)
+    f = np.float32
+    for d in range(nd):
+        for i in range(9 - ws):
+            for j in range(d, 12 - ws):
+                ml = f(0); mr = f(0)
+                for wh in range(ws):
+                    for ww in range(ws):
+                        ml = f(ml + f(l[i + wh, j + ww])); mr = f(mr + f(r[i + wh, j - d + ww]))
+                ml = f(ml / f(25)); mr = f(mr / f(25))
+                acc = f(0)
+                for wh in range(ws):
+                    for ww in range(ws):
+                        t = f(f(f(f(l[i + wh, j + ww]) - ml) - f(r[i + wh, j - d + ww])) + mr)
+                        acc = f(acc + abs(t))
+                assert got[d, i + wc, j + wc] == acc
+    assert got[1, 2, 2] == SENT                      # j = 0 < d = 1 never written
+
+
+def test_ncc_identical_windows_give_minus_one_and_flat_gives_one():
+    rng = np.random.default_rng(4)
+    l = rng.integers(0, 256, (12, 14), dtype=np.uint8)
+    n = O.nccNister(l, l.copy(), 2, 3)
+    assert np.allclose(n[0, 1:8, 1:10], -1.0, atol=1e-6)        # perfect correlation -> cost -1
+    flat = np.full((12, 14), 77, np.uint8)
+    n = O.nccNister(flat, flat, 2, 3)
+    assert np.all(n[0, 1:8, 1:10] == 1.0)                       # non-finite normaliser branch (matchers.cpp:203-204)
+
+
+def test_sadsob_matches_sequential_float32_integral():
+    rng = np.random.default_rng(5)
+    sl = rng.integers(-1020, 1021, (10, 13)).astype(np.float32)
+    sr = rng.integers(-1020, 1021, (10, 13)).astype(np.float32)
+    got = O.sadsob(sl, sr, 3, 5)
+    H, W = sl.shape
+    for d in range(3):
+        S = np.zeros((H + 1, W + 1), np.float32)
+        S[1:, d + 1:] = np.abs(sl[:, d:] - sr[:, :W - d])
+        S = np.cumsum(S, axis=0, dtype=np.float32)              # sequential float32 adds, columns then rows
+        S[:, d:] = np.cumsum(S[:, d:], axis=1, dtype=np.float32)
+        for i in range(H - 5):
+            for j in range(d, W - 5):
+                e = np.float32(np.float32(np.float32(S[i + 5, j + 5] - S[i + 5, j]) - S[i, j + 5]) + S[i, j])
+                assert got[d, i + 2, j + 2] == e
+
+
+def test_likelihood_properties():
+    rng = np.random.default_rng(6)
+    vol = (rng.random((50, 24), dtype=np.float32) * 100).astype(np.float32)
+    vol[3] = SENT
+    vol[7, 5:] = SENT
+    out = O.extract_likelihood(vol, 128.0)
+    assert not out[3].any()                                      # all-sentinel row -> zeros (featextract.cpp:452)
+    assert np.all(out[7, 5:] == 0) and abs(out[7].sum() - 1) < 1e-5
+    live = np.delete(np.arange(50), 3)
+    assert np.abs(out[live].sum(1) - 1).max() < 1e-5
+    assert np.all(out.argmax(1)[live] == vol.argmin(1)[live])    # the cheapest disparity is the most likely
+
+
+def test_swap_axes_and_volume_layout():
+    rng = np.random.default_rng(7)
+    c = rng.random((5, 6, 7), dtype=np.float32)
+    assert np.array_equal(O.swap_axes(c), c.transpose(1, 2, 0))
+    from msnets_amd import synthetic
+    l, r, drows = synthetic.stereo_pair(32, 64, 16, seed=1, bands=1)
+    vol = O.build_ms_volume(l, r, 16)
+    assert vol.shape == (8, 16, 32, 64) and vol.dtype == np.float32
+    assert vol.min() >= 0 and vol.max() <= 1
+    # channel 2 is the Sobel-SAD cost, channel 3 ZSAD (get_costs returns census, ncc, sobel, sad)
+    cs = O.get_costs(l, r, 16, 11, 3, 5, 5, 10, 10, 10)
+    assert np.array_equal(vol[2], (np.clip(cs[2], 0, 8192) / np.float32(8192)).transpose(2, 0, 1))
+    am = vol[0].argmin(0)
+    assert (am[:, 24:] == drows[:, None]).mean() > 0.95          # planted disparity recovered by census
+
+
+def test_sentinels_become_one_in_costs_and_zero_in_aml():
+    """SURVEY H3."""
+    from msnets_amd import synthetic
+    l, r, _ = synthetic.stereo_pair(32, 48, 16, seed=2)
+    vol = O.build_ms_volume(l, r, 16)
+    # cropped column x has census costs only for d <= x + 5
+    assert np.all(vol[0, 10:, :, 0] == 1.0) and np.all(vol[4, 10:, :, 0] == 0.0)
+    assert np.all(vol[3, 12:, :, 2] == 1.0)          # zsad: d <= x + 8
