@@ -5,7 +5,8 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_long, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmsnet_hip.so")
+# MSNET_HIP_LIB lets an A/B experiment point at another build of the same ABI (tools_layer_bench.py)
+LIB_PATH = os.environ.get("MSNET_HIP_LIB") or os.path.join(_HERE, "libmsnet_hip.so")
 _lib = None
 
 

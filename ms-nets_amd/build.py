@@ -39,9 +39,14 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force=False, verbose=True):
+def build(force=False, verbose=True, defines=(), lib=None):
+    """defines/lib: build an experiment variant (-D flags) into another .so without touching the shipped one."""
+    global LIB
     hipcc = _hipcc()
-    objdir = os.path.join(HERE, "build")
+    tag = "" if not defines else "_" + "_".join(d.replace("=", "") for d in defines)
+    objdir = os.path.join(HERE, "build" + tag)
+    if lib:
+        LIB = lib
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(HERE, "..", "include", "msnet_hip.h"),
                os.path.abspath(__file__)]
@@ -52,7 +57,7 @@ def build(force=False, verbose=True):
         op = os.path.join(objdir, src + ".o")
         objs.append(op)
         if force or _stale(op, [sp] + headers):
-            cmd = [hipcc, "-x", "hip"] + COMMON + extra + ["-c", sp, "-o", op]
+            cmd = [hipcc, "-x", "hip"] + COMMON + extra + ["-D" + d for d in defines] + ["-c", sp, "-o", op]
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
@@ -68,4 +73,6 @@ def build(force=False, verbose=True):
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    defs = [a[2:] for a in sys.argv[1:] if a.startswith("-D")]
+    out = [a[6:] for a in sys.argv[1:] if a.startswith("--lib=")]
+    build(force="--force" in sys.argv, defines=defs, lib=out[0] if out else None)

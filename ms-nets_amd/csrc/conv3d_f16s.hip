@@ -10,7 +10,8 @@
 // Requirement: |activation| < 65504 (fp16 range of `hi`); BN+ReLU activations of these nets are O(1..100).
 //
 // HBM layout is unchanged (fp32, channels-last): the LOADER waves split each staged fp32 voxel into the LDS image
-//   [voxel][ hi c0..c31 (64 B) | lo c0..c31 (64 B) | 16 B pad ]
+//   [voxel][ hi c0..c31 (64 B) | lo c0..c31 (64 B) ]      (128-byte records, 16-byte slots XOR-swizzled by (voxel>>1)&7
+//                                                        so the 16-lane groups of ds_read_b128 hit 16 distinct banks)
 // while the MFMA waves work, so no other kernel sees the fp16 form.  Weights are split once at pack time.
 //
 // Work distribution is the wave-specialised persistent scheme of conv3d.hip (4 MFMA waves + 4 loader waves per
@@ -26,6 +27,7 @@ namespace msnet {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // first-class vector (HIP's uint4 is a class)
 
 __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
@@ -70,21 +72,25 @@ __global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* _
     }
 }
 
-template <int TD, int TH, int TW, int BW, int MB, int NB>
+// SWZ = false: 144-byte voxel records (16 B pad): with 1x32-voxel M-blocks every ds_read_b128 lane group hits 16
+//               distinct bank slots and all fragment addresses are base + immediate (no VALU in the MFMA stream).
+// SWZ = true : 128-byte records with the 16-byte slots XOR-swizzled by (voxel>>1)&7 -- same conflict-freeness in
+//               13 KB less LDS (what lets the Co=64 weight double buffer fit), at ~6 VALU per fragment address.
+template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ>
 __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     constexpr int CC = 32;
     constexpr int BH = 32 / BW;
     constexpr int ID = TD + 2, IH = TH + 2, IW = TW + 2;
-    constexpr int RB = 144;                             // bytes per voxel record in LDS (64 hi + 64 lo + 16 pad)
+    constexpr int RB = SWZ ? 128 : 144;                 // bytes per voxel record in LDS (64 hi + 64 lo [+ 16 pad])
+    static_assert(BW == 32, "bank-conflict analysis assumes M-blocks of 32 consecutive voxels");
     constexpr int MW = TW / BW, MH = TH / BH;
     constexpr int V = CC / 4;
     constexpr int NPOS = ID * IH * IW;
-    constexpr int NSLOT = NPOS * V;
-    constexpr int NL = (NSLOT + 255) / 256;             // fp32 float4 per loader thread per tile
     constexpr int GB = 3 * 2 * NB * 2 * 1024;           // bytes of one weight group
     constexpr int NLB = GB / 16 / 256;                  // 16-byte pieces per loader thread per group
     static_assert(TD * MH * MW == 4 * MB, "M-block count mismatch");
-    static_assert(GB % (16 * 256) == 0, "group must split evenly over the loader threads");
+    static_assert(NLB == 3 || NLB == 6, "weight group = 3 or 6 16-byte pieces per loader thread");
+    static_assert(NPOS * RB + 2 * GB <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) unsigned char lds[NPOS * RB + 2 * GB];
     unsigned char* const lds_b = lds + NPOS * RB;
 
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     const int my_tiles = (T > lb) ? (int)((T - lb + G - 1) / G) : 0;
     const int nitems = my_tiles * nchunks;
     if (nitems == 0) return;
-    const uint4* wg = reinterpret_cast<const uint4*>(a.wpk);     // split-fp16 packed weights
+    const u32x4* wg = reinterpret_cast<const u32x4*>(a.wpk);     // split-fp16 packed weights
 
     auto decode = [&](int it, int& n, int& od0, int& oh0, int& ow0, int& chunk) {
         unsigned t = lb + (unsigned)(it / nchunks) * G;
@@ -112,82 +118,169 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     if (wave >= 4) {
         // ------------------------------ loader waves ------------------------------
         const int lt = tid - 256;
-        f32x4 av[NL];
-        uint4 bw[NLB];
-        auto issue_a = [&](int it) {
+        // three weight-group register sets as plain first-class vectors (a ring of HIP `uint4` class objects was kept in
+        // scratch by hipcc, putting a memory round trip and a vmcnt wait between the L2 load and the LDS copy)
+        struct BSet { u32x4 v0, v1, v2, v3, v4, v5; };
+        BSet bw0, bw1, bw2;
+        // The tile is staged one input depth-plane at a time (PL float4 per loader thread per plane) so that the
+        // copy of the NEXT tile into LDS can start before the current tile is finished: group order is kd-major, so
+        // plane 0 is dead after groups 0-2 and plane 1 after groups 3-5; only planes 2.. wait for the b1/b2 window.
+        // Per-slot constants (position inside a plane, global byte offset relative to the plane's tile origin, LDS
+        // offsets) are computed once; per item a slot costs one add + one buffer load (hardware range check returns 0
+        // for the lanes whose offset is forced out of range = conv zero padding / partial last slot).
+        constexpr int PSLOT = IH * IW * V;              // float4 per plane
+        constexpr int PL = (PSLOT + 255) / 256;
+        static_assert(ID == 4, "plane schedule below assumes TD == 2");
+        f32x4 av[ID][PL];
+        unsigned goff_[PL];                             // global byte offset of the slot from the plane tile origin
+        int ihw_[PL];                                   // (ih << 8) | iw, or -1 for a slot past the plane's end
+#pragma unroll
+        for (int u = 0; u < PL; ++u) {
+            const int slot = u * 256 + lt;
+            const int pos = slot / V, c4 = slot % V;
+            const int ih = pos / IW, iw = pos % IW;
+            const bool ok = slot < PSLOT;
+            goff_[u] = (unsigned)(((ih * a.W + iw) * a.Ci + c4 * 4) * 4);
+            ihw_[u] = ok ? ((ih << 8) | iw) : -1;
+        }
+        // LDS offset of this thread's slot u in plane pl: voxel = pl*IH*IW + u*32 + (lt>>3), channel quad c4 = lt & 7.
+        // The swizzle term (voxel>>1)&7 does not depend on u (u*32 is a multiple of 16), only on the plane.
+        static_assert((IH * IW) % 2 == 0, "plane size must be even for the per-plane swizzle below");
+        int lhi_[ID];                                   // offset of the hi half for u = 0
+#pragma unroll
+        for (int pl = 0; pl < ID; ++pl) {
+            const int p0 = lt >> 3, c4 = lt & 7;
+            const int sw = SWZ ? (((p0 >> 1) + pl * (IH * IW / 2)) & 7) : 0;
+            lhi_[pl] = (pl * IH * IW + p0) * RB + (c4 & 1) * 8 + (((c4 >> 1) ^ sw) << 4);
+        }
+        const size_t sample_bytes = (size_t)a.D * a.H * a.W * a.Ci * 4;
+
+        auto issue_a = [&](int it, int pl) {
             int n, od0, oh0, ow0, chunk;
             decode(it, n, od0, oh0, ow0, chunk);
-            const float* xc = a.x + chunk * CC;
+            const int gd = od0 - 1 + pl;
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.x) + (size_t)n * (sample_bytes / 4), 0, (int)sample_bytes, 0x00020000);
+            // byte offset of voxel (gd, oh0-1, ow0-1), channel chunk*32, inside the sample (may wrap below zero; the
+            // in-range lanes add a positive goff_ that brings it back -- unsigned arithmetic)
+            const unsigned base = (unsigned)((((long)gd * a.H + (oh0 - 1)) * a.W + (ow0 - 1)) * a.Ci + chunk * CC) * 4u;
+            const bool plane_ok = (unsigned)gd < (unsigned)a.D;
+            const bool interior = oh0 >= 1 && oh0 + TH + 1 <= a.H && ow0 >= 1 && ow0 + TW + 1 <= a.W;
 #pragma unroll
-            for (int u = 0; u < NL; ++u) {
-                const int slot = u * 256 + lt;
-                const int pos = slot / V, c4 = slot % V;
-                const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
-                const int gd = od0 - 1 + id, gh = oh0 - 1 + ih, gw = ow0 - 1 + iw;
-                av[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (slot < NSLOT && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H &&
-                    (unsigned)gw < (unsigned)a.W) {
-                    const size_t vox = (((size_t)n * a.D + gd) * a.H + gh) * a.W + gw;
-                    av[u] = *reinterpret_cast<const f32x4*>(xc + vox * a.Ci + c4 * 4);
+            for (int u = 0; u < PL; ++u) {
+                bool ok = ihw_[u] >= 0;
+                if (!interior) {
+                    const int gh = oh0 - 1 + (ihw_[u] >> 8), gw = ow0 - 1 + (ihw_[u] & 255);
+                    ok = ok && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
                 }
+                const unsigned voff = (ok && plane_ok) ? base + goff_[u] : 0xffffffffu;
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+                av[pl][u] = __builtin_bit_cast(f32x4, raw);
             }
         };
-        auto write_a = [&]() {
+        auto write_a = [&](int pl) {
 #pragma unroll
-            for (int u = 0; u < NL; ++u) {
-                const int slot = u * 256 + lt;
-                if (slot < NSLOT) {
+            for (int u = 0; u < PL; ++u) {
+                if (ihw_[u] >= 0) {
                     half4 hi, lo;
-                    split4(av[u], hi, lo);
-                    unsigned char* rec = lds + (slot / V) * RB + (slot % V) * 8;
-                    *reinterpret_cast<half4*>(rec) = hi;
-                    *reinterpret_cast<half4*>(rec + 64) = lo;
+                    split4(av[pl][u], hi, lo);
+                    const int off = lhi_[pl] + u * 32 * RB;
+                    *reinterpret_cast<half4*>(lds + off) = hi;
+                    *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ 64) : off + 64)) = lo;
                 }
             }
         };
-        auto issue_b = [&](int chunk, int grp) {
-            const uint4* src = wg + (size_t)(chunk * 9 + grp) * (GB / 16) + lt;
-#pragma unroll
-            for (int u = 0; u < NLB; ++u) bw[u] = src[u * 256];
+        // Weight groups form one endless stream k = it*9 + g (chunk = it % nchunks).  Group k lives in register set
+        // k % PD from the moment it is requested (while group k-PD-1 is multiplied, i.e. ~PD group times = several L2
+        // latencies earlier) until it is copied into LDS buffer k & 1 (while group k-1 is multiplied).
+        const int ngroups_total = nitems * 9;
+        auto b_src = [&](int k) {
+            k = k < ngroups_total ? k : ngroups_total - 1;     // past the end: harmless re-read
+            return wg + (size_t)(((k / 9) % nchunks) * 9 + (k % 9)) * (GB / 16) + lt;
         };
-        auto write_b = [&](int buf) {
-            uint4* dst = reinterpret_cast<uint4*>(lds_b + buf * GB) + lt;
-#pragma unroll
-            for (int u = 0; u < NLB; ++u) dst[u * 256] = bw[u];
-        };
+#define MSNET_ISSUE_B(K, SET)                                                                     \
+    do {                                                                                          \
+        const u32x4* src_ = b_src(K);                                                             \
+        SET.v0 = src_[0]; SET.v1 = src_[256]; SET.v2 = src_[512];                                 \
+        if constexpr (NLB > 3) { SET.v3 = src_[768]; SET.v4 = src_[1024]; SET.v5 = src_[1280]; }  \
+    } while (0)
+#define MSNET_WRITE_B(K, SET)                                                                     \
+    do {                                                                                          \
+        u32x4* dst_ = reinterpret_cast<u32x4*>(lds_b + ((K) & 1) * GB) + lt;                      \
+        dst_[0] = SET.v0; dst_[256] = SET.v1; dst_[512] = SET.v2;                                 \
+        if constexpr (NLB > 3) { dst_[768] = SET.v3; dst_[1024] = SET.v4; dst_[1280] = SET.v5; }  \
+    } while (0)
+#ifndef EXP_NO_GROUP_BARRIER
+#define MSNET_GROUP(G, SET)                     \
+    MSNET_WRITE_B(k0 + (G) + 1, SET);           \
+    MSNET_ISSUE_B(k0 + (G) + 1 + 3, SET);       \
+    MSNET_LDS_BARRIER();
+#else
+#define MSNET_GROUP(G, SET)                     \
+    MSNET_WRITE_B(k0 + (G) + 1, SET);           \
+    MSNET_ISSUE_B(k0 + (G) + 1 + 3, SET);
+#endif
 
-        issue_a(0);
-        issue_b(0, 0);
+        issue_a(0, 0); issue_a(0, 1); issue_a(0, 2); issue_a(0, 3);
+        MSNET_ISSUE_B(0, bw0);
+        MSNET_ISSUE_B(1, bw1);
+        MSNET_ISSUE_B(2, bw2);
+        bool early = false;                             // planes 0,1 of this item already copied during the previous one
         for (int it = 0; it < nitems; ++it) {
-            const int chunk = it % nchunks;
-            const int gg0 = it * 9;
+            const int k0 = it * 9;                      // 9 % 3 == 0: group k0+g always uses set g % 3
+            const bool more = it + 1 < nitems;
             MSNET_LDS_BARRIER();                        // b1: MFMA waves are done with the previous tile
-            write_a();
-            write_b(gg0 & 1);
+#ifndef EXP_NO_A_STAGE
+            if (!early) { write_a(0); write_a(1); }
+            write_a(2); write_a(3);
+#endif
+            MSNET_WRITE_B(k0, bw0);
+            MSNET_ISSUE_B(k0 + 3, bw0);
             MSNET_LDS_BARRIER();                        // b2: tile and group 0 are in LDS
-            issue_b(chunk, 1);
-            if (it + 1 < nitems) issue_a(it + 1);
-#pragma unroll 1
-            for (int g = 0; g < 8; ++g) {
-                write_b((gg0 + g + 1) & 1);             // group g+1, while group g is multiplied
-                if (g < 7) issue_b(chunk, g + 2);
-                else if (it + 1 < nitems) issue_b((it + 1) % nchunks, 0);
-                MSNET_LDS_BARRIER();                    // g_g
-            }
+            // group g+1 is copied to LDS (and group g+4 requested) while group g is multiplied; barrier g_g ends it.
+            // The next tile's planes are requested one per group and planes 0 / 1 copied as soon as they are dead.
+#ifndef EXP_NO_A_STAGE
+            if (more) issue_a(it + 1, 0);
+#endif
+            MSNET_GROUP(0, bw1)
+#ifndef EXP_NO_A_STAGE
+            if (more) issue_a(it + 1, 1);
+#endif
+            MSNET_GROUP(1, bw2)
+            MSNET_GROUP(2, bw0)                         // g_2 passed: kd = 0 groups done, plane 0 is dead
+#ifndef EXP_NO_A_STAGE
+            if (more) write_a(0);
+            if (more) issue_a(it + 1, 2);
+#endif
+            MSNET_GROUP(3, bw1)
+#ifndef EXP_NO_A_STAGE
+            if (more) issue_a(it + 1, 3);
+#endif
+            MSNET_GROUP(4, bw2)
+            MSNET_GROUP(5, bw0)                         // g_5 passed: kd = 1 groups done, plane 1 is dead
+#ifndef EXP_NO_A_STAGE
+            if (more) write_a(1);
+#endif
+            MSNET_GROUP(6, bw1)
+            MSNET_GROUP(7, bw2)
+            early = more;
         }
+#undef MSNET_GROUP
+#undef MSNET_WRITE_B
+#undef MSNET_ISSUE_B
         return;
     }
 
     // ------------------------------ MFMA waves ------------------------------
     const int wm = wave;                                // WM = 4, WN = 1
     const int r = lane & 31, hh = lane >> 5;
-    int abase[MB];                                      // byte offsets
+    int vox0[MB];                                       // LDS voxel index of this lane's output voxel (tap 0,0,0)
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
         const int mb = wm * MB + i;
         const int bw_ = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
         const int lh = bh * BH + r / BW, lw = bw_ * BW + r % BW;
-        abase[i] = ((bd * IH + lh) * IW + lw) * RB + 16 * hh;
+        vox0[i] = (bd * IH + lh) * IW + lw;
     }
     const int stride_w = a.Co, stride_h = a.OW * a.Co;
 
@@ -234,32 +327,50 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
                     for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
         }
         const int gg0 = it * 9;
-#pragma unroll 1
-        for (int g = 0; g < 9; ++g) {
-            const unsigned char* bb = lds_b + ((gg0 + g) & 1) * GB + lane * 16;
-            const int goff = ((g / 3) * IH + (g % 3)) * IW * RB;         // (kd, kh) row of this group
-            // 6 steps (t = kw tap, ks = 16-channel K-step); fragments of step s+1 are read while step s multiplies
-            half8 ah[2][MB], al[2][MB], bh_[2][NB], bl[2][NB];
-            auto frag = [&](int s, int slot) {
-                const int t = s >> 1, ks = s & 1;
+        // 6 steps per group (t = kw tap, ks = 16-channel K-step); fragments of step s+1 are read while step s multiplies.
+        // The tile is stable across the group barriers, so the A fragments of a group's first step are read BEFORE the
+        // barrier that publishes its weights; only the B fragments wait for it.
+        half8 ah[2][MB], al[2][MB], bh_[2][NB], bl[2][NB];
+        auto frag_a = [&](int s, int slot, int goff) {    // goff: voxel offset of the group's (kd, kh) row
+            const int t = s >> 1, ks = s & 1;
 #pragma unroll
-                for (int i = 0; i < MB; ++i) {
-                    const unsigned char* p = lds + abase[i] + goff + t * RB + ks * 32;
+            for (int i = 0; i < MB; ++i) {
+                if (SWZ) {
+                    const int vox = vox0[i] + goff + t;
+                    const int off = vox * RB + (((ks * 2 + hh) ^ ((vox >> 1) & 7)) << 4);
+                    ah[slot][i] = *reinterpret_cast<const half8*>(lds + off);
+                    al[slot][i] = *reinterpret_cast<const half8*>(lds + (off ^ 64));
+                } else {
+                    const unsigned char* p = lds + (vox0[i] + goff) * RB + 16 * hh + t * RB + ks * 32;
                     ah[slot][i] = *reinterpret_cast<const half8*>(p);
                     al[slot][i] = *reinterpret_cast<const half8*>(p + 64);
                 }
+            }
+        };
+        auto frag_b = [&](int s, int slot, const unsigned char* bb) {
+            const int t = s >> 1, ks = s & 1;
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const unsigned char* p = bb + (((t * 2 + ks) * NB + j) * 2) * 1024;
-                    bh_[slot][j] = *reinterpret_cast<const half8*>(p);
-                    bl[slot][j] = *reinterpret_cast<const half8*>(p + 1024);
-                }
-            };
-            frag(0, 0);
+            for (int j = 0; j < NB; ++j) {
+                const unsigned char* p = bb + (((t * 2 + ks) * NB + j) * 2) * 1024;
+                bh_[slot][j] = *reinterpret_cast<const half8*>(p);
+                bl[slot][j] = *reinterpret_cast<const half8*>(p + 1024);
+            }
+        };
+        frag_a(0, 0, 0);
+#pragma unroll 1
+        for (int g = 0; g < 9; ++g) {
+            const unsigned char* bb = lds_b + ((gg0 + g) & 1) * GB + lane * 16;
+            const int goff = ((g / 3) * IH + (g % 3)) * IW;              // (kd, kh) row of this group, in voxels
+            const int goff_next = (((g + 1) / 3) * IH + ((g + 1) % 3)) * IW;
+            frag_b(0, 0, bb);
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
-                if (s + 1 < 6) frag(s + 1, (s + 1) & 1);
+#ifndef EXP_NO_FRAG
+                if (s + 1 < 6) { frag_a(s + 1, (s + 1) & 1, goff); frag_b(s + 1, (s + 1) & 1, bb); }
+                else if (g < 8) frag_a(0, 0, goff_next);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
+#ifndef EXP_NO_MFMA
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
@@ -268,16 +379,24 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
                         acc1[i][j] = mfma16(al[s & 1][i], bh_[s & 1][j], acc1[i][j]);
                         acc1[i][j] = mfma16(ah[s & 1][i], bl[s & 1][j], acc1[i][j]);
                     }
+#else
+#pragma unroll
+                for (int i = 0; i < MB; ++i) asm volatile("" ::"v"(ah[s & 1][i]), "v"(al[s & 1][i]));
+#pragma unroll
+                for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(bh_[s & 1][j]), "v"(bl[s & 1][j]));
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
+#ifndef EXP_NO_GROUP_BARRIER
             if (g < 8) MSNET_LDS_BARRIER();             // g_g
+#endif
         }
         if (chunk == nchunks - 1) { pending = true; pn = n; pod0 = od0; poh0 = oh0; pow0 = ow0; }
     }
     if (pending) epilogue(pn, pod0, poh0, pow0);
 }
 
-template <int TD, int TH, int TW, int BW, int MB, int NB>
+template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ>
 static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     a.ntd = cdiv(a.OD, TD); a.nth = cdiv(a.OH, TH); a.ntw = cdiv(a.OW, TW);
     a.ngroups = 1; a.nbtot = a.Co / 32;
@@ -287,7 +406,7 @@ static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
                    4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB, SWZ>), dim3((unsigned)nblk), dim3(512), 0, s, a);
     return check_launch(name);
 }
 
@@ -327,6 +446,6 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
     a.OD = D; a.OH = H; a.OW = W;
     hipStream_t s = (hipStream_t)stream;
     //                                    TD TH TW  BW MB NB
-    if (Co == 64) return launch_f16s<2, 8, 16, 16, 2, 2>("conv3d_s1_f16s", a, s);
-    return launch_f16s<2, 8, 16, 16, 2, 1>("conv3d_s1_f16s", a, s);
+    if (Co == 64) return launch_f16s<2, 4, 32, 32, 2, 2, true>("conv3d_s1_f16s", a, s);
+    return launch_f16s<2, 4, 32, 32, 2, 1, false>("conv3d_s1_f16s", a, s);
 }

@@ -9,5 +9,5 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
 find $OUT/${TAG}_prof -name "*kernel_stats*" | head -3
 # keep only the small summaries
-find $OUT/${TAG}_prof -type f ! -name "*stats*" -delete
+find $OUT/${TAG}_prof -type f ! -name "*stats*" ! -name "*kernel_trace*" -delete
 echo round-done
