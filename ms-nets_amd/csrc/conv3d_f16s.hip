@@ -33,6 +33,18 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+#ifdef EXP_STAMP
+// Diagnostic build only: cycle stamps of block 0 (wave 0 = MFMA, wave 4 = loader) at every barrier of the first items.
+__device__ unsigned long long g_stamps[2][256];
+__device__ __forceinline__ void stamp(int role, int& idx, int lane) {
+    if (blockIdx.x == 0 && lane == 0 && idx < 256) g_stamps[role][idx] = __builtin_amdgcn_s_memtime();
+    ++idx;
+}
+#define STAMP(role, idx, lane) stamp(role, idx, lane)
+#else
+#define STAMP(role, idx, lane) do {} while (0)
+#endif
+
 constexpr float kLoScale = 2048.f;          // 2^11
 constexpr float kLoInv = 1.f / 2048.f;
 
@@ -45,13 +57,15 @@ __device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
     }
 }
 
-// Packed split weights, in 16-byte units:
-//   idx = ((((((chunk*9 + grp)*3 + t)*2 + ks)*NBT + nb)*2 + hl)*64 + lane
-//   element j of lane (r = lane&31, h = lane>>5):  W[co = nb*32 + r][ci = chunk*32 + ks*16 + h*8 + j][tap = grp*3 + t]
-//   hl = 0: fp16(w);  hl = 1: fp16((w - hi) * 2^11).           One group = 12*NBT KiB, contiguous.
+// Packed split weights, in 16-byte units (KS = 16-channel K-steps per chunk: 2 for Ci % 32 == 0, 1 for Ci = 8 which
+// is zero-padded to 16 channels):
+//   idx = ((((((chunk*9 + grp)*3 + t)*KS + ks)*NBT + nb)*2 + hl)*64 + lane
+//   element j of lane (r = lane&31, h = lane>>5):  W[co = nb*32 + r][ci = chunk*16*KS + ks*16 + h*8 + j][tap = grp*3 + t]
+//   hl = 0: fp16(w);  hl = 1: fp16((w - hi) * 2^11).           One group = 6*KS*NBT KiB, contiguous.
 template <bool TRANSPOSED>
-__global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Ci, int Co) {
-    const size_t total = (size_t)27 * Ci * Co * 2;
+__global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Ci, int Co, int KS) {
+    const int cip = Ci < 16 * KS ? 16 * KS : Ci;        // padded input channels
+    const size_t total = (size_t)27 * cip * Co * 2;
     const int nbt = Co >> 5;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
         size_t i = o;
@@ -59,14 +73,15 @@ __global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* _
         const int lane = i & 63; i >>= 6;
         const int hl = i & 1; i >>= 1;
         const int nb = i % nbt; i /= nbt;
-        const int ks = i & 1; i >>= 1;
+        const int ks = i % KS; i /= KS;
         const int t = i % 3; i /= 3;
         const int grp = i % 9;
         const int chunk = (int)(i / 9);
         const int co = nb * 32 + (lane & 31);
-        const int ci = chunk * 32 + ks * 16 + (lane >> 5) * 8 + j;
+        const int ci = chunk * 16 * KS + ks * 16 + (lane >> 5) * 8 + j;
         const int tap = grp * 3 + t;
-        const float v = TRANSPOSED ? w[((size_t)ci * Co + co) * 27 + tap] : w[((size_t)co * Ci + ci) * 27 + tap];
+        float v = 0.f;
+        if (ci < Ci) v = TRANSPOSED ? w[((size_t)ci * Co + co) * 27 + tap] : w[((size_t)co * Ci + ci) * 27 + tap];
         const _Float16 h = (_Float16)v;
         out[o] = hl ? (_Float16)((v - (float)h) * kLoScale) : h;
     }
@@ -76,22 +91,29 @@ __global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* _
 //               distinct bank slots and all fragment addresses are base + immediate (no VALU in the MFMA stream).
 // SWZ = true : 128-byte records with the 16-byte slots XOR-swizzled by (voxel>>1)&7 -- same conflict-freeness in
 //               13 KB less LDS (what lets the Co=64 weight double buffer fit), at ~6 VALU per fragment address.
-template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ>
+// KS = 16-channel K-steps per staged chunk: 2 (32-channel chunks) or 1 (the 8-channel first layer, zero-padded to 16).
+// RESB = true: all 27 taps of the (single-chunk) weight tensor stay resident in LDS for the whole kernel -- used when
+//               they fit beside the tile (the 8-channel layer: 54 KB): no weight streaming, 2 barriers per item instead of 10.
+template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB>
 __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
-    constexpr int CC = 32;
+    constexpr int CC = 16 * KS;
     constexpr int BH = 32 / BW;
     constexpr int ID = TD + 2, IH = TH + 2, IW = TW + 2;
-    constexpr int RB = SWZ ? 128 : 144;                 // bytes per voxel record in LDS (64 hi + 64 lo [+ 16 pad])
+    constexpr int HB = 2 * CC;                          // bytes of the hi (or lo) half of a voxel record
+    constexpr int RB = SWZ ? 2 * HB : 2 * HB + 16;      // bytes per voxel record in LDS (hi + lo [+ 16 pad])
+    static_assert(!SWZ || KS == 2, "the swizzle is written for 128-byte records");
     static_assert(BW == 32, "bank-conflict analysis assumes M-blocks of 32 consecutive voxels");
     constexpr int MW = TW / BW, MH = TH / BH;
     constexpr int V = CC / 4;
     constexpr int NPOS = ID * IH * IW;
-    constexpr int GB = 3 * 2 * NB * 2 * 1024;           // bytes of one weight group
-    constexpr int NLB = GB / 16 / 256;                  // 16-byte pieces per loader thread per group
+    constexpr int GB = 3 * KS * NB * 2 * 1024;          // bytes of one weight group
+    constexpr int PG = GB / 16;                         // 16-byte pieces per weight group
+    constexpr int NLB = (PG + 255) / 256;               // pieces per loader thread per group
     static_assert(TD * MH * MW == 4 * MB, "M-block count mismatch");
-    static_assert(NLB == 3 || NLB == 6, "weight group = 3 or 6 16-byte pieces per loader thread");
-    static_assert(NPOS * RB + 2 * GB <= 160 * 1024, "LDS budget");
-    __shared__ __attribute__((aligned(16))) unsigned char lds[NPOS * RB + 2 * GB];
+    static_assert(NLB == 2 || NLB == 3 || NLB == 6, "weight group = 2, 3 or 6 16-byte pieces per loader thread");
+    constexpr int NBUF = RESB ? 9 : 2;                  // weight-group buffers in LDS
+    static_assert(NPOS * RB + NBUF * GB <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPOS * RB + NBUF * GB];
     unsigned char* const lds_b = lds + NPOS * RB;
 
     const int tid = threadIdx.x;
@@ -99,7 +121,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     const int lane = tid & 63;
     const unsigned G = gridDim.x;
     const unsigned lb = xcd_remap(blockIdx.x, G);
-    const int nchunks = a.Ci / CC;
+    const int nchunks = a.Ci < CC ? 1 : a.Ci / CC;
     const unsigned T = (unsigned)a.N * a.ntd * a.nth * a.ntw;
     const int my_tiles = (T > lb) ? (int)((T - lb + G - 1) / G) : 0;
     const int nitems = my_tiles * nchunks;
@@ -117,6 +139,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
 
     if (wave >= 4) {
         // ------------------------------ loader waves ------------------------------
+        // (s_setprio(2) here was measured: the loader gets no faster and the MFMA groups slow down by ~10 %.)
         const int lt = tid - 256;
         // three weight-group register sets as plain first-class vectors (a ring of HIP `uint4` class objects was kept in
         // scratch by hipcc, putting a memory round trip and a vmcnt wait between the L2 load and the LDS copy)
@@ -139,38 +162,46 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
             const int slot = u * 256 + lt;
             const int pos = slot / V, c4 = slot % V;
             const int ih = pos / IW, iw = pos % IW;
-            const bool ok = slot < PSLOT;
+            const bool ok = slot < PSLOT && c4 * 4 < a.Ci;      // channels beyond Ci (first layer) are zero padding
             goff_[u] = (unsigned)(((ih * a.W + iw) * a.Ci + c4 * 4) * 4);
             ihw_[u] = ok ? ((ih << 8) | iw) : -1;
         }
-        // LDS offset of this thread's slot u in plane pl: voxel = pl*IH*IW + u*32 + (lt>>3), channel quad c4 = lt & 7.
-        // The swizzle term (voxel>>1)&7 does not depend on u (u*32 is a multiple of 16), only on the plane.
-        static_assert((IH * IW) % 2 == 0, "plane size must be even for the per-plane swizzle below");
+        // LDS offset of this thread's slot u in plane pl: voxel = pl*IH*IW + u*(256/V) + lt/V, channel quad c4 = lt % V.
+        // The swizzle term (voxel>>1)&7 does not depend on u (256/V is a multiple of 16), only on the plane.
+        static_assert((IH * IW) % 2 == 0 && (256 / V) % 16 == 0, "per-plane swizzle below");
         int lhi_[ID];                                   // offset of the hi half for u = 0
 #pragma unroll
         for (int pl = 0; pl < ID; ++pl) {
-            const int p0 = lt >> 3, c4 = lt & 7;
+            const int p0 = lt / V, c4 = lt % V;
             const int sw = SWZ ? (((p0 >> 1) + pl * (IH * IW / 2)) & 7) : 0;
             lhi_[pl] = (pl * IH * IW + p0) * RB + (c4 & 1) * 8 + (((c4 >> 1) ^ sw) << 4);
         }
         const size_t sample_bytes = (size_t)a.D * a.H * a.W * a.Ci * 4;
 
-        auto issue_a = [&](int it, int pl) {
-            int n, od0, oh0, ow0, chunk;
-            decode(it, n, od0, oh0, ow0, chunk);
-            const int gd = od0 - 1 + pl;
+        struct Coord { int n, od0, oh0, ow0, chunk; };
+        auto coord_of = [&](int it) {
+            Coord c;
+            decode(it, c.n, c.od0, c.oh0, c.ow0, c.chunk);
+            return c;
+        };
+        // request slots [u0, u1) of plane pl of the tile at c
+        auto issue_a = [&](const Coord& c, int pl, int u0, int u1) {
+            const int gd = c.od0 - 1 + pl;
             const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(a.x) + (size_t)n * (sample_bytes / 4), 0, (int)sample_bytes, 0x00020000);
-            // byte offset of voxel (gd, oh0-1, ow0-1), channel chunk*32, inside the sample (may wrap below zero; the
+                const_cast<float*>(a.x) + (size_t)c.n * (sample_bytes / 4), 0, (int)sample_bytes, 0x00020000);
+            // byte offset of voxel (gd, oh0-1, ow0-1), channel chunk*CC, inside the sample (may wrap below zero; the
             // in-range lanes add a positive goff_ that brings it back -- unsigned arithmetic)
-            const unsigned base = (unsigned)((((long)gd * a.H + (oh0 - 1)) * a.W + (ow0 - 1)) * a.Ci + chunk * CC) * 4u;
+            const unsigned base =
+                (unsigned)((((long)gd * a.H + (c.oh0 - 1)) * a.W + (c.ow0 - 1)) * a.Ci + c.chunk * CC) * 4u;
+            static_assert(PL * 256 >= PSLOT, "slots cover the plane");
             const bool plane_ok = (unsigned)gd < (unsigned)a.D;
-            const bool interior = oh0 >= 1 && oh0 + TH + 1 <= a.H && ow0 >= 1 && ow0 + TW + 1 <= a.W;
+            const bool interior = c.oh0 >= 1 && c.oh0 + TH + 1 <= a.H && c.ow0 >= 1 && c.ow0 + TW + 1 <= a.W;
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
+                if (u < u0 || u >= u1) continue;
                 bool ok = ihw_[u] >= 0;
                 if (!interior) {
-                    const int gh = oh0 - 1 + (ihw_[u] >> 8), gw = ow0 - 1 + (ihw_[u] & 255);
+                    const int gh = c.oh0 - 1 + (ihw_[u] >> 8), gw = c.ow0 - 1 + (ihw_[u] & 255);
                     ok = ok && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
                 }
                 const unsigned voff = (ok && plane_ok) ? base + goff_[u] : 0xffffffffu;
@@ -178,15 +209,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
                 av[pl][u] = __builtin_bit_cast(f32x4, raw);
             }
         };
-        auto write_a = [&](int pl) {
+        // split + copy slots [u0, u1) of plane pl into LDS
+        auto write_a = [&](int pl, int u0, int u1) {
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
-                if (ihw_[u] >= 0) {
+                if (u < u0 || u >= u1) continue;
+                if (u * 256 + lt < PSLOT) {             // padded channels are written too (as zeros)
                     half4 hi, lo;
                     split4(av[pl][u], hi, lo);
-                    const int off = lhi_[pl] + u * 32 * RB;
+                    const int off = lhi_[pl] + u * (256 / V) * RB;
                     *reinterpret_cast<half4*>(lds + off) = hi;
-                    *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ 64) : off + 64)) = lo;
+                    *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ 64) : off + HB)) = lo;
                 }
             }
         };
@@ -196,72 +229,126 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         const int ngroups_total = nitems * 9;
         auto b_src = [&](int k) {
             k = k < ngroups_total ? k : ngroups_total - 1;     // past the end: harmless re-read
-            return wg + (size_t)(((k / 9) % nchunks) * 9 + (k % 9)) * (GB / 16) + lt;
+            return wg + (size_t)(((k / 9) % nchunks) * 9 + (k % 9)) * PG;
         };
-#define MSNET_ISSUE_B(K, SET)                                                                     \
-    do {                                                                                          \
-        const u32x4* src_ = b_src(K);                                                             \
-        SET.v0 = src_[0]; SET.v1 = src_[256]; SET.v2 = src_[512];                                 \
-        if constexpr (NLB > 3) { SET.v3 = src_[768]; SET.v4 = src_[1024]; SET.v5 = src_[1280]; }  \
+        // piece index of this thread's u-th piece (clamped for the partial last piece of a 384-piece group)
+        int bi_[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) bi_[u] = (PG % 256 == 0 || u * 256 + lt < PG) ? u * 256 + lt : PG - 1;
+#define MSNET_ISSUE_B(K, SET)                                                                                      \
+    do {                                                                                                           \
+        const u32x4* src_ = b_src(K);                                                                              \
+        SET.v0 = src_[bi_[0]]; SET.v1 = src_[bi_[1]];                                                              \
+        if constexpr (NLB > 2) SET.v2 = src_[bi_[2]];                                                              \
+        if constexpr (NLB > 3) { SET.v3 = src_[768 + lt]; SET.v4 = src_[1024 + lt]; SET.v5 = src_[1280 + lt]; }    \
     } while (0)
-#define MSNET_WRITE_B(K, SET)                                                                     \
-    do {                                                                                          \
-        u32x4* dst_ = reinterpret_cast<u32x4*>(lds_b + ((K) & 1) * GB) + lt;                      \
-        dst_[0] = SET.v0; dst_[256] = SET.v1; dst_[512] = SET.v2;                                 \
-        if constexpr (NLB > 3) { dst_[768] = SET.v3; dst_[1024] = SET.v4; dst_[1280] = SET.v5; }  \
+#define MSNET_WRITE_B(K, SET)                                                                                      \
+    do {                                                                                                           \
+        u32x4* dst_ = reinterpret_cast<u32x4*>(lds_b + ((K) & 1) * GB);                                            \
+        dst_[bi_[0]] = SET.v0; dst_[bi_[1]] = SET.v1;                                                              \
+        if constexpr (NLB > 2) dst_[bi_[2]] = SET.v2;                                                              \
+        if constexpr (NLB > 3) { dst_[768 + lt] = SET.v3; dst_[1024 + lt] = SET.v4; dst_[1280 + lt] = SET.v5; }    \
     } while (0)
 #ifndef EXP_NO_GROUP_BARRIER
 #define MSNET_GROUP(G, SET)                     \
     MSNET_WRITE_B(k0 + (G) + 1, SET);           \
     MSNET_ISSUE_B(k0 + (G) + 1 + 3, SET);       \
-    MSNET_LDS_BARRIER();
+    if (wave == 4) STAMP(1, sidx, lane);        \
+    MSNET_LDS_BARRIER();                        \
+    if (wave == 4) STAMP(1, sidx, lane);
 #else
 #define MSNET_GROUP(G, SET)                     \
     MSNET_WRITE_B(k0 + (G) + 1, SET);           \
     MSNET_ISSUE_B(k0 + (G) + 1 + 3, SET);
 #endif
 
-        issue_a(0, 0); issue_a(0, 1); issue_a(0, 2); issue_a(0, 3);
+        if constexpr (RESB) {
+            // weights: one pass, all 9 groups, before the first tile is published
+            for (int k = 0; k < 9; ++k) {
+                const u32x4* src = wg + (size_t)k * PG;
+                u32x4* dst = reinterpret_cast<u32x4*>(lds_b + k * GB);
+                for (int p = lt; p < PG; p += 256) dst[p] = src[p];
+            }
+            {
+                const Coord c0 = coord_of(0);
+#pragma unroll
+                for (int pl = 0; pl < ID; ++pl) issue_a(c0, pl, 0, PL);
+            }
+            for (int it = 0; it < nitems; ++it) {
+                MSNET_LDS_BARRIER();                    // b1
+#pragma unroll
+                for (int pl = 0; pl < ID; ++pl) write_a(pl, 0, PL);
+                MSNET_LDS_BARRIER();                    // b2
+                if (it + 1 < nitems) {
+                    const Coord c = coord_of(it + 1);
+#pragma unroll
+                    for (int pl = 0; pl < ID; ++pl) issue_a(c, pl, 0, PL);
+                }
+            }
+            return;
+        }
+        {
+            const Coord c0 = coord_of(0);
+#pragma unroll
+            for (int pl = 0; pl < ID; ++pl) issue_a(c0, pl, 0, PL);
+        }
         MSNET_ISSUE_B(0, bw0);
         MSNET_ISSUE_B(1, bw1);
         MSNET_ISSUE_B(2, bw2);
         bool early = false;                             // planes 0,1 of this item already copied during the previous one
+        int sidx = 0;
+        // The loader shares each SIMD with an MFMA wave and runs ~3x slower than alone, so its per-item work (28 loads,
+        // 28 split+copy, 27 weight pieces) is spread evenly over the nine group slots instead of bunched at the barriers.
+        constexpr int H0 = (PL + 2) / 3, H1 = (2 * PL + 2) / 3, HH = (PL + 1) / 2;
         for (int it = 0; it < nitems; ++it) {
             const int k0 = it * 9;                      // 9 % 3 == 0: group k0+g always uses set g % 3
             const bool more = it + 1 < nitems;
+            if (wave == 4) STAMP(1, sidx, lane);
             MSNET_LDS_BARRIER();                        // b1: MFMA waves are done with the previous tile
+            if (wave == 4) STAMP(1, sidx, lane);
 #ifndef EXP_NO_A_STAGE
-            if (!early) { write_a(0); write_a(1); }
-            write_a(2); write_a(3);
+            if (!early) { write_a(0, 0, PL); write_a(1, 0, PL); }
+            write_a(2, 0, PL); write_a(3, 0, PL);
 #endif
             MSNET_WRITE_B(k0, bw0);
             MSNET_ISSUE_B(k0 + 3, bw0);
+            if (wave == 4) STAMP(1, sidx, lane);
             MSNET_LDS_BARRIER();                        // b2: tile and group 0 are in LDS
+            if (wave == 4) STAMP(1, sidx, lane);
             // group g+1 is copied to LDS (and group g+4 requested) while group g is multiplied; barrier g_g ends it.
-            // The next tile's planes are requested one per group and planes 0 / 1 copied as soon as they are dead.
+            // The next tile is requested during groups 0-2; its planes 0 / 1 are copied as soon as they are dead.
+            Coord nx = coord_of(more ? it + 1 : it);
 #ifndef EXP_NO_A_STAGE
-            if (more) issue_a(it + 1, 0);
+            if (more) { issue_a(nx, 0, 0, PL); issue_a(nx, 1, 0, HH); }
 #endif
             MSNET_GROUP(0, bw1)
 #ifndef EXP_NO_A_STAGE
-            if (more) issue_a(it + 1, 1);
+            if (more) { issue_a(nx, 1, HH, PL); issue_a(nx, 2, 0, PL); }
 #endif
             MSNET_GROUP(1, bw2)
+#ifndef EXP_NO_A_STAGE
+            if (more) issue_a(nx, 3, 0, PL);
+#endif
             MSNET_GROUP(2, bw0)                         // g_2 passed: kd = 0 groups done, plane 0 is dead
 #ifndef EXP_NO_A_STAGE
-            if (more) write_a(0);
-            if (more) issue_a(it + 1, 2);
+            if (more) write_a(0, 0, H0);
 #endif
             MSNET_GROUP(3, bw1)
 #ifndef EXP_NO_A_STAGE
-            if (more) issue_a(it + 1, 3);
+            if (more) write_a(0, H0, H1);
 #endif
             MSNET_GROUP(4, bw2)
+#ifndef EXP_NO_A_STAGE
+            if (more) write_a(0, H1, PL);
+#endif
             MSNET_GROUP(5, bw0)                         // g_5 passed: kd = 1 groups done, plane 1 is dead
 #ifndef EXP_NO_A_STAGE
-            if (more) write_a(1);
+            if (more) write_a(1, 0, HH);
 #endif
             MSNET_GROUP(6, bw1)
+#ifndef EXP_NO_A_STAGE
+            if (more) write_a(1, HH, PL);
+#endif
             MSNET_GROUP(7, bw2)
             early = more;
         }
@@ -312,12 +399,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         }
     };
 
+    int sidx = 0;
     for (int it = 0; it < nitems; ++it) {
         int n, od0, oh0, ow0, chunk;
         decode(it, n, od0, oh0, ow0, chunk);
+        if (wave == 0) STAMP(0, sidx, lane);
         MSNET_LDS_BARRIER();                            // b1
+        if (wave == 0) STAMP(0, sidx, lane);
         if (pending) { epilogue(pn, pod0, poh0, pow0); pending = false; }
+        if (wave == 0) STAMP(0, sidx, lane);
         MSNET_LDS_BARRIER();                            // b2
+        if (wave == 0) STAMP(0, sidx, lane);
         if (chunk == 0) {
 #pragma unroll
             for (int i = 0; i < MB; ++i)
@@ -327,12 +419,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
                     for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
         }
         const int gg0 = it * 9;
-        // 6 steps per group (t = kw tap, ks = 16-channel K-step); fragments of step s+1 are read while step s multiplies.
+        // 3*KS steps per group (t = kw tap, ks = 16-channel K-step); fragments of step s+1 are read while step s multiplies.
         // The tile is stable across the group barriers, so the A fragments of a group's first step are read BEFORE the
         // barrier that publishes its weights; only the B fragments wait for it.
-        half8 ah[2][MB], al[2][MB], bh_[2][NB], bl[2][NB];
+        constexpr int NS = 3 * KS;
+        // Fragment ring of R slots: R = 3 (two steps of look-ahead) where registers allow, else 2.  Step s of any group
+        // uses slot s % R (NS % R == 0), so the A fragments of the next group's first R-1 steps can be read before the
+        // barrier that publishes its weights.
+        constexpr int R = (NB == 1 || KS == 1) ? 3 : 2;
+        constexpr int PF = R - 1;
+        static_assert(NS % R == 0 && PF <= NS, "fragment ring must tile the group");
+        half8 ah[R][MB], al[R][MB], bh_[R][NB], bl[R][NB];
         auto frag_a = [&](int s, int slot, int goff) {    // goff: voxel offset of the group's (kd, kh) row
-            const int t = s >> 1, ks = s & 1;
+            const int t = s / KS, ks = s % KS;
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 if (SWZ) {
@@ -343,31 +442,33 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
                 } else {
                     const unsigned char* p = lds + (vox0[i] + goff) * RB + 16 * hh + t * RB + ks * 32;
                     ah[slot][i] = *reinterpret_cast<const half8*>(p);
-                    al[slot][i] = *reinterpret_cast<const half8*>(p + 64);
+                    al[slot][i] = *reinterpret_cast<const half8*>(p + HB);
                 }
             }
         };
         auto frag_b = [&](int s, int slot, const unsigned char* bb) {
-            const int t = s >> 1, ks = s & 1;
+            const int t = s / KS, ks = s % KS;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const unsigned char* p = bb + (((t * 2 + ks) * NB + j) * 2) * 1024;
+                const unsigned char* p = bb + (((t * KS + ks) * NB + j) * 2) * 1024;
                 bh_[slot][j] = *reinterpret_cast<const half8*>(p);
                 bl[slot][j] = *reinterpret_cast<const half8*>(p + 1024);
             }
         };
-        frag_a(0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < PF; ++q) frag_a(q, q, 0);
 #pragma unroll 1
         for (int g = 0; g < 9; ++g) {
-            const unsigned char* bb = lds_b + ((gg0 + g) & 1) * GB + lane * 16;
+            const unsigned char* bb = lds_b + (RESB ? g : ((gg0 + g) & 1)) * GB + lane * 16;
             const int goff = ((g / 3) * IH + (g % 3)) * IW;              // (kd, kh) row of this group, in voxels
             const int goff_next = (((g + 1) / 3) * IH + ((g + 1) % 3)) * IW;
-            frag_b(0, 0, bb);
 #pragma unroll
-            for (int s = 0; s < 6; ++s) {
+            for (int q = 0; q < PF; ++q) frag_b(q, q, bb);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
 #ifndef EXP_NO_FRAG
-                if (s + 1 < 6) { frag_a(s + 1, (s + 1) & 1, goff); frag_b(s + 1, (s + 1) & 1, bb); }
-                else if (g < 8) frag_a(0, 0, goff_next);
+                if (s + PF < NS) { frag_a(s + PF, (s + PF) % R, goff); frag_b(s + PF, (s + PF) % R, bb); }
+                else if (g < 8) frag_a(s + PF - NS, (s + PF) % R, goff_next);
 #endif
                 __builtin_amdgcn_sched_barrier(0);
 #ifndef EXP_NO_MFMA
@@ -375,20 +476,24 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
-                        acc0[i][j] = mfma16(ah[s & 1][i], bh_[s & 1][j], acc0[i][j]);
-                        acc1[i][j] = mfma16(al[s & 1][i], bh_[s & 1][j], acc1[i][j]);
-                        acc1[i][j] = mfma16(ah[s & 1][i], bl[s & 1][j], acc1[i][j]);
+                        acc0[i][j] = mfma16(ah[s % R][i], bh_[s % R][j], acc0[i][j]);
+                        acc1[i][j] = mfma16(al[s % R][i], bh_[s % R][j], acc1[i][j]);
+                        acc1[i][j] = mfma16(ah[s % R][i], bl[s % R][j], acc1[i][j]);
                     }
 #else
 #pragma unroll
-                for (int i = 0; i < MB; ++i) asm volatile("" ::"v"(ah[s & 1][i]), "v"(al[s & 1][i]));
+                for (int i = 0; i < MB; ++i) asm volatile("" ::"v"(ah[s % R][i]), "v"(al[s % R][i]));
 #pragma unroll
-                for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(bh_[s & 1][j]), "v"(bl[s & 1][j]));
+                for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(bh_[s % R][j]), "v"(bl[s % R][j]));
 #endif
                 __builtin_amdgcn_sched_barrier(0);
             }
 #ifndef EXP_NO_GROUP_BARRIER
-            if (g < 8) MSNET_LDS_BARRIER();             // g_g
+            if (!RESB && g < 8) {
+                if (wave == 0) STAMP(0, sidx, lane);
+                MSNET_LDS_BARRIER();                    // g_g
+                if (wave == 0) STAMP(0, sidx, lane);
+            }
 #endif
         }
         if (chunk == nchunks - 1) { pending = true; pn = n; pod0 = od0; poh0 = oh0; pow0 = ow0; }
@@ -396,7 +501,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     if (pending) epilogue(pn, pod0, poh0, pow0);
 }
 
-template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ>
+template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB>
 static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     a.ntd = cdiv(a.OD, TD); a.nth = cdiv(a.OH, TH); a.ntw = cdiv(a.OW, TW);
     a.ngroups = 1; a.nbtot = a.Co / 32;
@@ -406,7 +511,7 @@ static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
                    4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB, SWZ>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB, SWZ, KS, RESB>), dim3((unsigned)nblk), dim3(512), 0, s, a);
     return check_launch(name);
 }
 
@@ -414,23 +519,30 @@ static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
 
 using namespace msnet;
 
-// Split-fp16 packed size in floats (same byte count as the fp32 packing: 2 halves per weight).
+#ifdef EXP_STAMP
+extern "C" int msnet_debug_read_stamps(unsigned long long* host) {
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : 1;
+}
+#endif
+
+// Split-fp16 packed size: 27 * max(Ci,16) * Co floats (2 halves per weight; Ci = 8 is zero-padded to 16 channels).
 extern "C" int msnet_pack_conv_weight_f16s(const float* w, void* packed, int Ci, int Co, int transposed,
                                            msnet_stream_t stream) {
     if (!w || !packed) return fail("msnet_pack_conv_weight_f16s: null pointer");
-    if (Ci <= 0 || Ci % 32 != 0) return fail("msnet_pack_conv_weight_f16s: Ci=%d must be a positive multiple of 32", Ci);
+    if (!(Ci == 8 || (Ci > 0 && Ci % 32 == 0))) return fail("msnet_pack_conv_weight_f16s: Ci=%d must be 8 or a multiple of 32", Ci);
+    const int KS = Ci == 8 ? 1 : 2;
     if (Co <= 0 || Co % 32 != 0) return fail("msnet_pack_conv_weight_f16s: Co=%d must be a positive multiple of 32", Co);
-    const size_t total = (size_t)27 * Ci * Co * 2;
+    const size_t total = (size_t)27 * (Ci < 16 ? 16 : Ci) * Co * 2;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipStream_t s = (hipStream_t)stream;
     LaunchScope ls("pack_weight_f16s", s, 0, 6.0 * total);
-    if (transposed) hipLaunchKernelGGL(pack_weight_f16s_kernel<true>, dim3(blocks), dim3(256), 0, s, w, (_Float16*)packed, Ci, Co);
-    else            hipLaunchKernelGGL(pack_weight_f16s_kernel<false>, dim3(blocks), dim3(256), 0, s, w, (_Float16*)packed, Ci, Co);
+    if (transposed) hipLaunchKernelGGL(pack_weight_f16s_kernel<true>, dim3(blocks), dim3(256), 0, s, w, (_Float16*)packed, Ci, Co, KS);
+    else            hipLaunchKernelGGL(pack_weight_f16s_kernel<false>, dim3(blocks), dim3(256), 0, s, w, (_Float16*)packed, Ci, Co, KS);
     return check_launch("msnet_pack_conv_weight_f16s");
 }
 
 extern "C" int msnet_conv3d_k3_f16s_supported(int Ci, int Co, int stride) {
-    return (stride == 1 && Ci > 0 && Ci % 32 == 0 && (Co == 32 || Co == 64)) ? 1 : 0;
+    return (stride == 1 && (Ci == 8 || (Ci > 0 && Ci % 32 == 0)) && (Co == 32 || Co == 64)) ? 1 : 0;
 }
 
 extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const float* scale, const float* shift,
@@ -446,6 +558,10 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
     a.OD = D; a.OH = H; a.OW = W;
     hipStream_t s = (hipStream_t)stream;
     //                                    TD TH TW  BW MB NB
-    if (Co == 64) return launch_f16s<2, 4, 32, 32, 2, 2, true>("conv3d_s1_f16s", a, s);
-    return launch_f16s<2, 4, 32, 32, 2, 1, false>("conv3d_s1_f16s", a, s);
+    if (Ci == 8) {
+        if (Co == 64) return launch_f16s<2, 4, 32, 32, 2, 2, false, 1, false>("conv3d_s1_c8_f16s", a, s);
+        return launch_f16s<2, 6, 32, 32, 3, 1, false, 1, true>("conv3d_s1_c8_f16s", a, s);
+    }
+    if (Co == 64) return launch_f16s<2, 4, 32, 32, 2, 2, true, 2, false>("conv3d_s1_f16s", a, s);
+    return launch_f16s<2, 4, 32, 32, 2, 1, false, 2, false>("conv3d_s1_f16s", a, s);
 }

@@ -32,7 +32,8 @@ def pack_conv_weight(w, transposed=False, f16s=False):
         raise ValueError("only 3x3x3 kernels are built (got %s)" % (tuple(w.shape),))
     ci, co = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
     lib = _lib.load()
-    out = torch.empty(lib.msnet_packed_weight_floats(ci, co), device=w.device, dtype=torch.float32)
+    out = torch.empty(lib.msnet_packed_weight_floats(max(ci, 16) if f16s else ci, co), device=w.device,
+                      dtype=torch.float32)
     if f16s:
         check(lib.msnet_pack_conv_weight_f16s(ptr(w), ptr(out), ci, co, int(transposed), stream_ptr()),
               "msnet_pack_conv_weight_f16s")

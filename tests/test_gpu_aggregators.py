@@ -58,6 +58,9 @@ CONV_CASES = [
 
 
 F16S_CASES = [
+    (8, 32, (1, 6, 10, 37), True, False),
+    (8, 32, (2, 4, 8, 32), False, True),
+    (8, 64, (1, 3, 5, 33), True, False),
     (32, 32, (1, 4, 9, 40), True, False),
     (32, 32, (2, 3, 8, 16), True, True),
     (32, 64, (1, 5, 6, 19), True, False),
