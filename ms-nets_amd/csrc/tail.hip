@@ -32,29 +32,34 @@ struct SoftArg {
     __device__ __forceinline__ float result() const { return t / s; }
 };
 
-// Stage one depth slice (IH x IW voxels x CI channels, origin (h0,w0)) of an NDHWC tensor into LDS [pos][CI+4].
-template <int CI, int IH, int IW>
-__device__ __forceinline__ void stage_slice(float* lds, const float* __restrict__ x, size_t slice_base, int H, int W,
-                                            int h0, int w0, int tid) {
-    constexpr int PS = CI + 4, V = CI / 4, NSLOT = IH * IW * V, U = 4;
-    for (int base = 0; base < NSLOT; base += 256 * U) {
-        f32x4 v[U];
+// One depth slice (IH x IW voxels x CI channels, origin (h0,w0)) of an NDHWC tensor, staged into LDS [pos][CI+4] in two
+// halves so the HBM latency of slice P+1 hides under the arithmetic on slice P (registers hold it meanwhile):
+//   slice_load  : global -> NR float4 registers per thread (voxels outside the tensor read as zero)
+//   slice_store : registers -> LDS
+template <int CI, int IH, int IW, int NT>
+struct SliceStage {
+    static constexpr int PS = CI + 4, V = CI / 4, NSLOT = IH * IW * V, NR = (NSLOT + NT - 1) / NT;
+    f32x4 v[NR];
+    __device__ __forceinline__ void load(const float* __restrict__ x, size_t slice_base, int H, int W, int h0, int w0,
+                                         int tid, bool live) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int slot = base + u * 256 + tid;
+        for (int u = 0; u < NR; ++u) {
+            const int slot = u * NT + tid;
             const int pos = slot / V, c4 = slot % V;
             const int gh = h0 + pos / IW, gw = w0 + pos % IW;
             v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (slot < NSLOT && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+            if (live && slot < NSLOT && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
                 v[u] = *reinterpret_cast<const f32x4*>(x + (slice_base + (size_t)gh * W + gw) * CI + c4 * 4);
         }
+    }
+    __device__ __forceinline__ void store(float* lds, int tid) const {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int slot = base + u * 256 + tid;
+        for (int u = 0; u < NR; ++u) {
+            const int slot = u * NT + tid;
             if (slot < NSLOT) *reinterpret_cast<f32x4*>(lds + (slot / V) * PS + (slot % V) * 4) = v[u];
         }
     }
-}
+};
 
 // ---------------------------------------------------------------------------------------------
 // deconv5 + softmax + disparity regression.  Thread = one input column (h', w'), i.e. the 2x2 output
@@ -64,12 +69,18 @@ __device__ __forceinline__ void stage_slice(float* lds, const float* __restrict_
 // so each staged slice yields three partial sums per output pixel (kd = 0,1,2); the kd=2 partial is
 // carried to the next slice.  27*CI MACs per input voxel, exactly the dense definition.
 // ---------------------------------------------------------------------------------------------
-template <int CI, bool WRITE_LOGITS>
-__global__ __launch_bounds__(256) void deconv5_tail_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           float bias, float* __restrict__ out, int N, int D, int H,
-                                                           int W, int nth, int ntw) {
-    constexpr int TH = 8, TW = 32, IH = TH + 1, IW = TW + 1, PS = CI + 4;
+template <int CI, bool WRITE_LOGITS, int TH>
+__global__ __launch_bounds__(TH * 32) void deconv5_tail_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               float bias, float* __restrict__ out, int N, int D, int H,
+                                                               int W, int nth, int ntw) {
+    constexpr int TW = 32, IH = TH + 1, IW = TW + 1, PS = CI + 4, NT = TH * 32;
     __shared__ __attribute__((aligned(16))) float lds[IH * IW * PS];
+    // The 27*CI weights are wave-uniform.  As SGPR operands they cost ~55 exposed scalar-cache round trips per slice
+    // (SMEM returns out of order => lgkmcnt(0) each batch): 20K cycles per wave-slice for 880 FMAs (r01g: 1.84 ms).
+    // A padded LDS table read by broadcast ds_read_b128 (7 per channel) pipelines under counted lgkmcnt instead.
+    __shared__ __attribute__((aligned(16))) float wlds[CI * 28];
+    for (int k = threadIdx.x; k < CI * 28; k += NT) wlds[k] = (k % 28 < 27) ? w[(k / 28) * 27 + k % 28] : 0.f;
+    SliceStage<CI, IH, IW, NT> stg;
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tw = bid % ntw; bid /= ntw;
     const int th = bid % nth;
@@ -84,6 +95,7 @@ __global__ __launch_bounds__(256) void deconv5_tail_kernel(const float* __restri
     float carry[4] = {0.f, 0.f, 0.f, 0.f};
     const bool live = (h < H) && (wq < W);
 
+    stg.load(x, (size_t)n * D * H * W, H, W, h0, w0, tid, true);
     for (int P = 0; P <= D; ++P) {
         float p[3][4];
 #pragma unroll
@@ -91,11 +103,12 @@ __global__ __launch_bounds__(256) void deconv5_tail_kernel(const float* __restri
 #pragma unroll
             for (int c = 0; c < 4; ++c) p[kd][c] = 0.f;
         if (P < D) {
+            __syncthreads();                            // everyone is done reading slice P-1
+            stg.store(lds, tid);
             __syncthreads();
-            stage_slice<CI, IH, IW>(lds, x, ((size_t)n * D + P) * H * W, H, W, h0, w0, tid);
-            __syncthreads();
-#pragma unroll
-            for (int c4 = 0; c4 < CI / 4; ++c4) {
+            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0, w0, tid, P + 1 < D);   // in flight during the FMAs
+#pragma unroll 1
+            for (int c4 = 0; c4 < CI / 4; ++c4) {     // rolled: a full unroll keeps hundreds of weights live (1 wave/SIMD)
                 f32x4 xv[2][2];
 #pragma unroll
                 for (int dh = 0; dh < 2; ++dh)
@@ -104,7 +117,12 @@ __global__ __launch_bounds__(256) void deconv5_tail_kernel(const float* __restri
                         xv[dh][dw] = *reinterpret_cast<const f32x4*>(lds + ((lh + dh) * IW + lw + dw) * PS + c4 * 4);
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
-                    const float* wc = w + (c4 * 4 + cc) * 27;
+                    float wc[28];
+#pragma unroll
+                    for (int k4 = 0; k4 < 7; ++k4) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(wlds + (c4 * 4 + cc) * 28 + k4 * 4);
+                        wc[k4 * 4] = t4[0]; wc[k4 * 4 + 1] = t4[1]; wc[k4 * 4 + 2] = t4[2]; wc[k4 * 4 + 3] = t4[3];
+                    }
 #pragma unroll
                     for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
@@ -161,6 +179,9 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict
                                                          int D, int H, int W, int nth, int ntw) {
     constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, PS = CI + 4;
     __shared__ __attribute__((aligned(16))) float lds[IH * IW * PS];
+    __shared__ __attribute__((aligned(16))) float wlds[CI * 28];    // weight table, see deconv5_tail_kernel
+    for (int k = threadIdx.x; k < CI * 28; k += 256) wlds[k] = (k % 28 < 27) ? w[(k / 28) * 27 + k % 28] : 0.f;
+    SliceStage<CI, IH, IW, 256> stg;
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tw = bid % ntw; bid /= ntw;
     const int th = bid % nth;
@@ -169,13 +190,15 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict
     const int h0 = th * TH, w0 = tw * TW, h = h0 + lh, wq = w0 + lw;
     const bool live = (h < H) && (wq < W);
     float r1 = 0.f, r0 = 0.f;
+    stg.load(x, (size_t)n * D * H * W, H, W, h0 - 1, w0 - 1, tid, true);
     for (int P = 0; P <= D; ++P) {
         float q[3] = {0.f, 0.f, 0.f};
         if (P < D) {
             __syncthreads();
-            stage_slice<CI, IH, IW>(lds, x, ((size_t)n * D + P) * H * W, H, W, h0 - 1, w0 - 1, tid);
+            stg.store(lds, tid);
             __syncthreads();
-#pragma unroll
+            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0 - 1, w0 - 1, tid, P + 1 < D);
+#pragma unroll 1
             for (int c4 = 0; c4 < CI / 4; ++c4) {
                 f32x4 xv[3][3];
 #pragma unroll
@@ -185,7 +208,12 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict
                         xv[kh][kw] = *reinterpret_cast<const f32x4*>(lds + ((lh + kh) * IW + lw + kw) * PS + c4 * 4);
 #pragma unroll
                 for (int cc = 0; cc < 4; ++cc) {
-                    const float* wc = w + (c4 * 4 + cc) * 27;
+                    float wc[28];
+#pragma unroll
+                    for (int k4 = 0; k4 < 7; ++k4) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(wlds + (c4 * 4 + cc) * 28 + k4 * 4);
+                        wc[k4 * 4] = t4[0]; wc[k4 * 4 + 1] = t4[1]; wc[k4 * 4 + 2] = t4[2]; wc[k4 * 4 + 3] = t4[3];
+                    }
 #pragma unroll
                     for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
@@ -315,12 +343,13 @@ extern "C" int msnet_deconv5_softargmin(const float* x, const float* w, float bi
     if (!x || !w || !disp) return fail("msnet_deconv5_softargmin: null pointer");
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_deconv5_softargmin: empty input");
     if (Ci != 32) return fail("msnet_deconv5_softargmin: Ci=%d (only 32 is built)", Ci);
-    const int nth = cdiv(H, 8), ntw = cdiv(W, 32);
+    constexpr int TH = 4;       // 4x32 input columns / 128 threads per workgroup: 1020 workgroups at 272x480, 6 per CU
+    const int nth = cdiv(H, TH), ntw = cdiv(W, 32);
     hipStream_t s = (hipStream_t)stream;
     const double vox = (double)N * D * H * W;
     LaunchScope ls("deconv5_softargmin", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + 4.0 * N * H * W));
-    hipLaunchKernelGGL((deconv5_tail_kernel<32, false>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, bias,
-                       disp, N, D, H, W, nth, ntw);
+    hipLaunchKernelGGL((deconv5_tail_kernel<32, false, TH>), dim3((unsigned)(N * nth * ntw)), dim3(TH * 32), 0, s, x, w,
+                       bias, disp, N, D, H, W, nth, ntw);
     return check_launch("msnet_deconv5_softargmin");
 }
 
@@ -334,7 +363,7 @@ extern "C" int msnet_deconv3d_cout1(const float* x, const float* w, float bias, 
     if (stride == 2 && Ci == 32) {
         const int nth = cdiv(H, 8), ntw = cdiv(W, 32);
         LaunchScope ls("deconv5_logits", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + 8.0 * vox));
-        hipLaunchKernelGGL((deconv5_tail_kernel<32, true>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w,
+        hipLaunchKernelGGL((deconv5_tail_kernel<32, true, 8>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w,
                            bias, logits, N, D, H, W, nth, ntw);
         return check_launch("msnet_deconv3d_cout1");
     }
