@@ -53,14 +53,26 @@ def gcnet_flops(H, W, D):
     return 2.0 * mac
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is; both in KB) -- measured once per round on the same
+    workload with tools_pmc.sh, not re-measured by the timed run.  None if no measurement is committed."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_dominant.json")
+    try:
+        d = json.load(open(path))
+        return d["hbm_bytes_per_launch"] if d.get("kernel_key") in kernel_name else None
+    except Exception:
+        return None
+
+
 def cpu_baseline(seed=0):
     """The oracle (CPU port of the same path: C matchers + NumPy glue + torch fp32 aggregator) on a bounded
-    sample: the cfg#2 depth (D'=96) on a 272x240 half-res crop (half of the 272x480 voxels).  Throughput is
+    sample: ONE full cfg#2 map (272x480 half-res, D'=96), single run, no warm-up.  Throughput is
     scaled to full maps by the voxel ratio (every stage is linear in H'*W')."""
     from msnets_amd import synthetic
     from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre
     from oracle import aggregators, ms_volume
-    hs, ws, nd = 272, 240, 96
+    hs, ws, nd = 272, 480, 96
     cores = min(os.cpu_count() or 1, 64)     # MKL-DNN conv3d stops scaling (and regresses) far below 256 threads
     torch.set_num_threads(cores)
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
@@ -155,8 +167,11 @@ def main():
     if rank == 0:
         maps = n_total * args.steps
         # dominant kernel = the stride-1 conv3d family: split-fp16 MFMA when that precision is active, else fp32 MFMA
-        if "conv3d_s1_f16s" in prof:
-            dom_name, dom = "conv3d_k3s1_f16s_ws (split-fp16 MFMA, 3 MFMAs per product)", prof["conv3d_s1_f16s"]
+        f16 = {k: v for k, v in prof.items() if k.startswith("conv3d_s1_f16s")}
+        if f16:
+            # the single largest launch family: Co=32 instantiation = conv3dbn_2 (32->32 at full half-res), once per map
+            key = "conv3d_s1_f16s_co32" if "conv3d_s1_f16s_co32" in f16 else max(f16, key=lambda k: f16[k]["ms"])
+            dom_name, dom = "conv3d_k3s1_f16s_ws / %s (split-fp16 MFMA, 3 MFMAs per product)" % key, f16[key]
             peak = FP16_MATRIX_PEAK_TFLOPS / SPLIT_MFMAS_PER_PRODUCT
             peak_note = "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product"
         else:
@@ -180,7 +195,7 @@ def main():
                          "time_share_of_step": dom["ms"] / (1e3 * dt) if dt > 0 else 0.0,
                          "launches": dom["calls"], "avg_launch_ms": dom["ms"] / max(1, dom["calls"]),
                          "all_conv_tflops": conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0,
-                         "traffic": None},
+                         "traffic": pmc_traffic(dom_name)},
         }
         if args.verbose:
             tot = sum(v["ms"] for v in prof.values())

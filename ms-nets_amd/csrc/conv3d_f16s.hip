@@ -562,6 +562,6 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
         if (Co == 64) return launch_f16s<2, 4, 32, 32, 2, 2, false, 1, false>("conv3d_s1_c8_f16s", a, s);
         return launch_f16s<2, 6, 32, 32, 3, 1, false, 1, true>("conv3d_s1_c8_f16s", a, s);
     }
-    if (Co == 64) return launch_f16s<2, 4, 32, 32, 2, 2, true, 2, false>("conv3d_s1_f16s", a, s);
-    return launch_f16s<2, 4, 32, 32, 2, 1, false, 2, false>("conv3d_s1_f16s", a, s);
+    if (Co == 64) return launch_f16s<2, 4, 32, 32, 2, 2, true, 2, false>("conv3d_s1_f16s_co64", a, s);
+    return launch_f16s<2, 4, 32, 32, 2, 1, false, 2, false>("conv3d_s1_f16s_co32", a, s);
 }
