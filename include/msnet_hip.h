@@ -119,6 +119,12 @@ int msnet_conv3d_k3_f16s_supported(int Ci, int Co, int stride);
 int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const float* scale, const float* shift,
                          const float* residual, float* y, int N, int D, int H, int W, int Ci, int Co,
                          int stride, int relu, msnet_stream_t stream);
+/* Split-fp16 fast path of msnet_deconv3d_k3s2 (same contract); supported for Ci = 64, Co in {32, 64}. */
+int msnet_deconv3d_k3s2_f16s_supported(int Ci, int Co);
+int msnet_pack_deconv_weight_f16s(const float* w, void* packed, int Ci, int Co, msnet_stream_t stream);
+int msnet_deconv3d_k3s2_f16s(const float* x, const void* wpk_f16s, const float* scale, const float* shift,
+                             const float* residual, float* y, int N, int D, int H, int W, int Ci, int Co,
+                             int relu, msnet_stream_t stream);
 /* deconvbn_3d: ConvTranspose3d(k3,s2,p1,op1) + BN (+ residual) (+ReLU).  gcnet_3dcnn.py:24-27,
  * psmnet_3dcnn.py:41-44,63-67.  x: [N][D][H][W][Ci] -> y: [N][2D][2H][2W][Co]. */
 int msnet_deconv3d_k3s2(const float* x, const float* wpk, const float* scale, const float* shift,

@@ -21,9 +21,21 @@
 //     loader :  |b1| write A_it, B_(it,0) |b2|  write B_1   |g0|  write B_2   |g1| ...   |g7|
 //     compute:  |b1| epilogue(it-1)       |b2|  MFMA grp 0  |g0|  MFMA grp 1  |g1| ...   |g7| MFMA grp 8
 // Group g+1's weights are written while group g is being multiplied; the barrier that ends group g publishes them.
+#include <utility>
+
 #include "conv_common.h"
 
 namespace msnet {
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N-1>{})
+template <class F, int... Ks>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, Ks...>) {
+    (f(std::integral_constant<int, Ks>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
@@ -59,14 +71,18 @@ __device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
 
 // Packed split weights, in 16-byte units (KS = 16-channel K-steps per chunk: 2 for Ci % 32 == 0, 1 for Ci = 8 which
 // is zero-padded to 16 channels):
-//   idx = ((((((chunk*9 + grp)*3 + t)*KS + ks)*NBT + nb)*2 + hl)*64 + lane
-//   element j of lane (r = lane&31, h = lane>>5):  W[co = nb*32 + r][ci = chunk*16*KS + ks*16 + h*8 + j][tap = grp*3 + t]
-//   hl = 0: fp16(w);  hl = 1: fp16((w - hi) * 2^11).           One group = 6*KS*NBT KiB, contiguous.
+//   idx = (((((((cg*nchunks + chunk)*9 + grp)*3 + t)*KS + ks)*NBG + nbl)*2 + hl)*64 + lane
+//   element j of lane (r = lane&31, h = lane>>5):
+//       W[co = (cg*NBG + nbl)*32 + r][ci = chunk*16*KS + ks*16 + h*8 + j][tap = grp*3 + t]
+//   hl = 0: fp16(w);  hl = 1: fp16((w - hi) * 2^11).   NBG = N-blocks per output-channel group (a workgroup handles one
+//   group: 1 block for Co = 32, 2 for Co = 64 / 128).  One weight group = 6*KS*NBG KiB, contiguous.
 template <bool TRANSPOSED>
-__global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Ci, int Co, int KS) {
+__global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Ci, int Co, int KS,
+                                        int NBG) {
     const int cip = Ci < 16 * KS ? 16 * KS : Ci;        // padded input channels
     const size_t total = (size_t)27 * cip * Co * 2;
-    const int nbt = Co >> 5;
+    const int nbt = NBG;
+    const int nchunks = cip / (16 * KS);
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
         size_t i = o;
         const int j = i & 7; i >>= 3;
@@ -75,9 +91,10 @@ __global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* _
         const int nb = i % nbt; i /= nbt;
         const int ks = i % KS; i /= KS;
         const int t = i % 3; i /= 3;
-        const int grp = i % 9;
-        const int chunk = (int)(i / 9);
-        const int co = nb * 32 + (lane & 31);
+        const int grp = i % 9; i /= 9;
+        const int chunk = i % nchunks;
+        const int cg = (int)(i / nchunks);
+        const int co = (cg * NBG + nb) * 32 + (lane & 31);
         const int ci = chunk * 16 * KS + ks * 16 + (lane >> 5) * 8 + j;
         const int tap = grp * 3 + t;
         float v = 0.f;
@@ -122,15 +139,26 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     const unsigned G = gridDim.x;
     const unsigned lb = xcd_remap(blockIdx.x, G);
     const int nchunks = a.Ci < CC ? 1 : a.Ci / CC;
-    const unsigned T = (unsigned)a.N * a.ntd * a.nth * a.ntw;
+    const int ncg = a.ngroups;                          // output-channel groups of 32*NB channels
+    const unsigned T = (unsigned)a.N * a.ntd * a.nth * a.ntw * ncg;
     const int my_tiles = (T > lb) ? (int)((T - lb + G - 1) / G) : 0;
     const int nitems = my_tiles * nchunks;
     if (nitems == 0) return;
     const u32x4* wg = reinterpret_cast<const u32x4*>(a.wpk);     // split-fp16 packed weights
 
+    auto decode_g = [&](int it, int& n, int& od0, int& oh0, int& ow0, int& chunk, int& cg) {
+        unsigned t = lb + (unsigned)(it / nchunks) * G;
+        chunk = it % nchunks;
+        cg = t % ncg; t /= ncg;
+        ow0 = (t % a.ntw) * TW; t /= a.ntw;
+        oh0 = (t % a.nth) * TH; t /= a.nth;
+        od0 = (t % a.ntd) * TD;
+        n = t / a.ntd;
+    };
     auto decode = [&](int it, int& n, int& od0, int& oh0, int& ow0, int& chunk) {
         unsigned t = lb + (unsigned)(it / nchunks) * G;
         chunk = it % nchunks;
+        t /= ncg;
         ow0 = (t % a.ntw) * TW; t /= a.ntw;
         oh0 = (t % a.nth) * TH; t /= a.nth;
         od0 = (t % a.ntd) * TD;
@@ -229,7 +257,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         const int ngroups_total = nitems * 9;
         auto b_src = [&](int k) {
             k = k < ngroups_total ? k : ngroups_total - 1;     // past the end: harmless re-read
-            return wg + (size_t)(((k / 9) % nchunks) * 9 + (k % 9)) * PG;
+            const int it_ = k / 9;
+            const unsigned cg = ncg == 1 ? 0u : (lb + (unsigned)(it_ / nchunks) * G) % (unsigned)ncg;
+            return wg + (size_t)((cg * nchunks + (it_ % nchunks)) * 9 + (k % 9)) * PG;
         };
         // piece index of this thread's u-th piece (clamped for the partial last piece of a 384-piece group)
         int bi_[3];
@@ -264,7 +294,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
 
         if constexpr (RESB) {
             // weights: one pass, all 9 groups, before the first tile is published
-            for (int k = 0; k < 9; ++k) {
+            for (int k = 0; k < 9; ++k) {               // (RESB is only used with a single channel group and chunk)
                 const u32x4* src = wg + (size_t)k * PG;
                 u32x4* dst = reinterpret_cast<u32x4*>(lds_b + k * GB);
                 for (int p = lt; p < PG; p += 256) dst[p] = src[p];
@@ -372,10 +402,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     const int stride_w = a.Co, stride_h = a.OW * a.Co;
 
     f32x16 acc0[MB][NB], acc1[MB][NB];
-    int pn = 0, pod0 = 0, poh0 = 0, pow0 = 0;           // coordinates of the item whose epilogue is pending
+    int pn = 0, pod0 = 0, poh0 = 0, pow0 = 0, pcg = 0;  // coordinates of the item whose epilogue is pending
     bool pending = false;
 
-    auto epilogue = [&](int n, int od0, int oh0, int ow0) {
+    auto epilogue = [&](int n, int od0, int oh0, int ow0, int cg) {
         const bool full_hw = (oh0 + TH <= a.OH) && (ow0 + TW <= a.OW);
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
@@ -386,7 +416,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
             const int ohb = oh0 + bh * BH, owb = ow0 + bw_ * BW + 4 * hh;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                const int co = j * 32 + r;
+                const int co = (cg * NB + j) * 32 + r;
                 const float sc = a.scale ? a.scale[co] : 1.f;
                 const float sh = a.shift ? a.shift[co] : 0.f;
                 f32x16 v;
@@ -401,12 +431,12 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
 
     int sidx = 0;
     for (int it = 0; it < nitems; ++it) {
-        int n, od0, oh0, ow0, chunk;
-        decode(it, n, od0, oh0, ow0, chunk);
+        int n, od0, oh0, ow0, chunk, cg;
+        decode_g(it, n, od0, oh0, ow0, chunk, cg);
         if (wave == 0) STAMP(0, sidx, lane);
         MSNET_LDS_BARRIER();                            // b1
         if (wave == 0) STAMP(0, sidx, lane);
-        if (pending) { epilogue(pn, pod0, poh0, pow0); pending = false; }
+        if (pending) { epilogue(pn, pod0, poh0, pow0, pcg); pending = false; }
         if (wave == 0) STAMP(0, sidx, lane);
         MSNET_LDS_BARRIER();                            // b2
         if (wave == 0) STAMP(0, sidx, lane);
@@ -496,16 +526,319 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
             }
 #endif
         }
-        if (chunk == nchunks - 1) { pending = true; pn = n; pod0 = od0; poh0 = oh0; pow0 = ow0; }
+        if (chunk == nchunks - 1) { pending = true; pn = n; pod0 = od0; poh0 = oh0; pow0 = ow0; pcg = cg; }
     }
-    if (pending) epilogue(pn, pod0, poh0, pow0);
+    if (pending) epilogue(pn, pod0, poh0, pow0, pcg);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transposed conv (k3, s2, p1, op1) on the split-fp16 MFMA.  Same decomposition as deconv3d_k3s2_mfma (8 output-parity
+// classes sharing one LDS tile of INPUT voxels, 27 (class, tap) pairs = the dense definition's MACs) and the same
+// wave-specialised persistent scheme as the forward conv above.  Differences:
+//   * the tile holds ALL input channels (CI = 16*KS, records of 4*CI bytes + 16 pad), so classes can be finished one
+//     after another with a single accumulator pair; a tile is staged once and used by all 27 weight groups;
+//   * a weight group is one (class, tap): KS K-steps x NB x (hi, lo) KiB pairs, double-buffered in LDS, streamed by the
+//     loader waves three groups ahead; one barrier per group;
+//   * after the last tap of a class the MFMA waves run that class's strided epilogue (+ residual, ReLU).
+// Work item = (input tile 2x4x32, output-channel group of 32*NB).
+// ---------------------------------------------------------------------------------------------
+struct DTap { int pd, ph, pw, dd, dh, dw, kd, kh, kw, last; };
+__host__ __device__ constexpr DTap dtap(int k) {
+    // class order 7,6,5,3,4,2,1,0 (8,4,4,4,2,2,2,1 taps); taps of a class in (dd, dh, dw) order
+    constexpr int order[8] = {7, 6, 5, 3, 4, 2, 1, 0};
+    int base = 0;
+    for (int c = 0; c < 8; ++c) {
+        const int cls = order[c];
+        const int pd = cls >> 2, ph = (cls >> 1) & 1, pw = cls & 1;
+        const int nt = (pd + 1) * (ph + 1) * (pw + 1);
+        if (k < base + nt) {
+            const int tp = k - base;
+            const int dw = tp % (pw + 1), dh = (tp / (pw + 1)) % (ph + 1), dd = tp / ((pw + 1) * (ph + 1));
+            return DTap{pd, ph, pw, dd, dh, dw, pd ? (dd ? 0 : 2) : 1, ph ? (dh ? 0 : 2) : 1, pw ? (dw ? 0 : 2) : 1,
+                        tp == nt - 1};
+        }
+        base += nt;
+    }
+    return DTap{0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
+}
+
+// packed deconv weights (16-byte units): idx = ((((cg*27 + k)*KS + ks)*NB + nbl)*2 + hl)*64 + lane, k = group in dtap order,
+// element j of lane (r, h): W[ci = ks*16 + h*8 + j][co = (cg*NB + nbl)*32 + r][tap = (kd*3+kh)*3+kw]   (ConvTranspose3d layout)
+__global__ void pack_deconv_weight_f16s_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Ci, int Co,
+                                               int KS, int NB) {
+    const size_t total = (size_t)27 * Ci * Co * 2;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        size_t i = o;
+        const int j = i & 7; i >>= 3;
+        const int lane = i & 63; i >>= 6;
+        const int hl = i & 1; i >>= 1;
+        const int nbl = i % NB; i /= NB;
+        const int ks = i % KS; i /= KS;
+        const int k = i % 27;
+        const int cg = (int)(i / 27);
+        const DTap t = dtap(k);
+        const int co = (cg * NB + nbl) * 32 + (lane & 31);
+        const int ci = ks * 16 + (lane >> 5) * 8 + j;
+        const float v = w[((size_t)ci * Co + co) * 27 + (t.kd * 3 + t.kh) * 3 + t.kw];
+        const _Float16 h = (_Float16)v;
+        out[o] = hl ? (_Float16)((v - (float)h) * kLoScale) : h;
+    }
+}
+
+template <int KS, int NB>
+__global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
+    constexpr int TD = 2, TH = 4, TW = 32, MB = 2;
+    constexpr int CI = 16 * KS;
+    constexpr int ID = TD + 1, IH = TH + 1, IW = TW + 1;
+    constexpr int HB = 2 * CI;                          // bytes of the hi (or lo) half of a voxel record
+    constexpr int RB = 2 * HB + 16;                     // odd number of 16-byte slots => conflict-free 1x32 M-blocks
+    constexpr int V = CI / 4;
+    constexpr int NPOS = ID * IH * IW;
+    constexpr int NSLOT = NPOS * V;
+    constexpr int NL = (NSLOT + 255) / 256;             // fp32 float4 per loader thread per tile
+    constexpr int GB = KS * NB * 2 * 1024;              // bytes of one weight group (one tap)
+    constexpr int PG = GB / 16;
+    constexpr int NLB = PG / 256;                       // 16-byte pieces per loader thread per group
+    static_assert(PG % 256 == 0 && (NLB == 1 || NLB == 2 || NLB == 4), "weight group pieces per loader thread");
+    static_assert(NPOS * RB + 2 * GB <= 160 * 1024, "LDS budget");
+    __shared__ __attribute__((aligned(16))) unsigned char lds[NPOS * RB + 2 * GB];
+    unsigned char* const lds_b = lds + NPOS * RB;
+
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const unsigned G = gridDim.x;
+    const unsigned lb = xcd_remap(blockIdx.x, G);
+    const int ncg = a.ngroups;                          // output-channel groups of 32*NB
+    const unsigned T = (unsigned)a.N * a.ntd * a.nth * a.ntw * ncg;
+    const int nitems = (T > lb) ? (int)((T - lb + G - 1) / G) : 0;
+    if (nitems == 0) return;
+    const u32x4* wg = reinterpret_cast<const u32x4*>(a.wpk);
+
+    auto decode = [&](int it, int& n, int& d0, int& h0, int& w0, int& cg) {
+        unsigned t = lb + (unsigned)it * G;
+        cg = t % ncg; t /= ncg;
+        w0 = (t % a.ntw) * TW; t /= a.ntw;
+        h0 = (t % a.nth) * TH; t /= a.nth;
+        d0 = (t % a.ntd) * TD;
+        n = t / a.ntd;
+    };
+
+    if (wave >= 4) {
+        // ------------------------------ loader waves ------------------------------
+        const int lt = tid - 256;
+        struct BSet { u32x4 v0, v1, v2, v3; };
+        BSet bw0, bw1, bw2;
+        f32x4 av[NL];
+        const size_t sample_bytes = (size_t)a.D * a.H * a.W * a.Ci * 4;
+        auto issue_a = [&](int it) {
+            int n, d0, h0, w0, cg;
+            decode(it, n, d0, h0, w0, cg);
+            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(a.x) + (size_t)n * (sample_bytes / 4), 0, (int)sample_bytes, 0x00020000);
+            const unsigned base = (unsigned)((((long)d0 * a.H + h0) * a.W + w0) * a.Ci) * 4u;
+            int ltv = lt;
+            asm volatile("" : "+v"(ltv));               // keep the per-slot index math inside the loop (registers)
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const int slot = u * 256 + ltv;
+                const int pos = slot / V, c4 = slot % V;
+                const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
+                const bool ok = slot < NSLOT && d0 + id < a.D && h0 + ih < a.H && w0 + iw < a.W;
+                const unsigned voff = ok ? base + (unsigned)((((id * a.H + ih) * a.W + iw) * a.Ci + c4 * 4) * 4) : 0xffffffffu;
+                av[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+            }
+        };
+        auto write_a = [&]() {
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const int slot = u * 256 + lt;
+                if (slot < NSLOT) {
+                    half4 hi, lo;
+                    split4(av[u], hi, lo);
+                    unsigned char* rec = lds + (slot / V) * RB + (slot % V) * 8;
+                    *reinterpret_cast<half4*>(rec) = hi;
+                    *reinterpret_cast<half4*>(rec + HB) = lo;
+                }
+            }
+        };
+        // weight groups: endless stream k = it*27 + g; group k uses register set k % 3 (27 % 3 == 0) and LDS buffer k & 1
+        const int ngroups_total = nitems * 27;
+        int b_item = 0;                                 // item whose group is cg_cur
+        int cg_cur = 0, cg_next = 0;                    // output-channel group of the current / next item
+        auto cg_of = [&](int it) {
+            int n, d0, h0, w0, cg;
+            decode(it < nitems ? it : nitems - 1, n, d0, h0, w0, cg);
+            return cg;
+        };
+        auto b_src = [&](int k) {                       // k - k0 is a compile-time constant at every call site
+            const int k0_ = (k / 27) * 27;
+            (void)k0_;
+            k = k < ngroups_total ? k : ngroups_total - 1;
+            const int gi = k % 27;
+            const int cg = (k / 27 == b_item) ? cg_cur : cg_next;
+            return wg + (size_t)(cg * 27 + gi) * PG + lt;
+        };
+#define MSNET_ISSUE_B(K, SET)                                                                     \
+    do {                                                                                          \
+        const u32x4* src_ = b_src(K);                                                             \
+        SET.v0 = src_[0];                                                                         \
+        if constexpr (NLB > 1) SET.v1 = src_[256];                                                \
+        if constexpr (NLB > 2) { SET.v2 = src_[512]; SET.v3 = src_[768]; }                        \
+    } while (0)
+#define MSNET_WRITE_B(K, SET)                                                                     \
+    do {                                                                                          \
+        u32x4* dst_ = reinterpret_cast<u32x4*>(lds_b + ((K) & 1) * GB) + lt;                      \
+        dst_[0] = SET.v0;                                                                         \
+        if constexpr (NLB > 1) dst_[256] = SET.v1;                                                \
+        if constexpr (NLB > 2) { dst_[512] = SET.v2; dst_[768] = SET.v3; }                        \
+    } while (0)
+#define MSNET_DGROUP(G, SET)                    \
+    MSNET_WRITE_B(k0 + (G) + 1, SET);           \
+    MSNET_ISSUE_B(k0 + (G) + 1 + 3, SET);       \
+    MSNET_LDS_BARRIER();
+        issue_a(0);
+        cg_cur = cg_of(0); cg_next = cg_of(1);
+        MSNET_ISSUE_B(0, bw0);
+        MSNET_ISSUE_B(1, bw1);
+        MSNET_ISSUE_B(2, bw2);
+        for (int it = 0; it < nitems; ++it) {
+            const int k0 = it * 27;
+            if (it > 0) { b_item = it; cg_cur = cg_next; cg_next = cg_of(it + 1); }
+            MSNET_LDS_BARRIER();                        // b1: MFMA waves are done with the previous tile
+            write_a();
+            MSNET_WRITE_B(k0, bw0);
+            MSNET_ISSUE_B(k0 + 3, bw0);
+            MSNET_LDS_BARRIER();                        // b2: tile and group 0 are in LDS
+            if (it + 1 < nitems) issue_a(it + 1);
+            MSNET_DGROUP(0, bw1)  MSNET_DGROUP(1, bw2)  MSNET_DGROUP(2, bw0)  MSNET_DGROUP(3, bw1)  MSNET_DGROUP(4, bw2)
+            MSNET_DGROUP(5, bw0)  MSNET_DGROUP(6, bw1)  MSNET_DGROUP(7, bw2)  MSNET_DGROUP(8, bw0)  MSNET_DGROUP(9, bw1)
+            MSNET_DGROUP(10, bw2) MSNET_DGROUP(11, bw0) MSNET_DGROUP(12, bw1) MSNET_DGROUP(13, bw2) MSNET_DGROUP(14, bw0)
+            MSNET_DGROUP(15, bw1) MSNET_DGROUP(16, bw2) MSNET_DGROUP(17, bw0) MSNET_DGROUP(18, bw1) MSNET_DGROUP(19, bw2)
+            MSNET_DGROUP(20, bw0) MSNET_DGROUP(21, bw1) MSNET_DGROUP(22, bw2) MSNET_DGROUP(23, bw0) MSNET_DGROUP(24, bw1)
+            MSNET_DGROUP(25, bw2)
+        }
+#undef MSNET_DGROUP
+#undef MSNET_WRITE_B
+#undef MSNET_ISSUE_B
+        return;
+    }
+
+    // ------------------------------ MFMA waves ------------------------------
+    const int wm = wave;
+    const int r = lane & 31, hh = lane >> 5;
+    int abase[MB];                                      // byte offset of this lane's input voxel record (+ lane-half slot)
+#pragma unroll
+    for (int i = 0; i < MB; ++i) {
+        const int mb = wm * MB + i;                     // M-block = (bd, bh) row of 32 input voxels
+        const int bh = mb % TH, bd = mb / TH;
+        abase[i] = ((bd * IH + bh) * IW + r) * RB + 16 * hh;
+    }
+    const int stride_w = 2 * a.Co, stride_h = 2 * a.OW * a.Co;
+
+    for (int it = 0; it < nitems; ++it) {
+        int n, d0, h0, w0, cg;
+        decode(it, n, d0, h0, w0, cg);
+        const int nb0 = cg * NB;
+        MSNET_LDS_BARRIER();                            // b1
+        MSNET_LDS_BARRIER();                            // b2
+        const int gg0 = it * 27;
+        f32x16 acc0[MB][NB], acc1[MB][NB];
+        half8 ah[2][MB], al[2][MB], bh_[2][NB], bl[2][NB];
+        // the 27 groups are expanded at compile time (a 27-trip `#pragma unroll` was only partially honoured, leaving
+        // dtap() -- loops and divisions -- and the accumulator/fragment indexing to run time: 2.7 ms instead of 2.0)
+        static_for<27>([&](auto kc) {
+            constexpr int k = decltype(kc)::value;
+            constexpr DTap t = dtap(k);
+            constexpr bool first = (k == 0) || dtap(k > 0 ? k - 1 : 0).last;
+            if (first) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+            }
+            const unsigned char* bb = lds_b + ((gg0 + k) & 1) * GB + lane * 16;
+            const int toff = ((t.dd * IH + t.dh) * IW + t.dw) * RB;
+            auto frag = [&](int ks, int slot) {
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const unsigned char* p = lds + abase[i] + toff + ks * 32;
+                    ah[slot][i] = *reinterpret_cast<const half8*>(p);
+                    al[slot][i] = *reinterpret_cast<const half8*>(p + HB);
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const unsigned char* p = bb + ((ks * NB + j) * 2) * 1024;
+                    bh_[slot][j] = *reinterpret_cast<const half8*>(p);
+                    bl[slot][j] = *reinterpret_cast<const half8*>(p + 1024);
+                }
+            };
+            frag(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if (ks + 1 < KS) frag(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < MB; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        acc0[i][j] = mfma16(ah[ks & 1][i], bh_[ks & 1][j], acc0[i][j]);
+                        acc1[i][j] = mfma16(al[ks & 1][i], bh_[ks & 1][j], acc1[i][j]);
+                        acc1[i][j] = mfma16(ah[ks & 1][i], bl[ks & 1][j], acc1[i][j]);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (k < 26) MSNET_LDS_BARRIER();            // g_k: this group's weights are consumed, the next are published
+            if (t.last) {
+                // epilogue of class (pd, ph, pw): output voxel (2*id+pd, 2*ih+ph, 2*iw+pw)
+                const bool full_hw = (h0 + TH <= a.H) && (w0 + TW <= a.W);
+#pragma unroll
+                for (int i = 0; i < MB; ++i) {
+                    const int mb = wm * MB + i;
+                    const int bh = mb % TH, bd = mb / TH;
+                    const int id = d0 + bd;
+                    if (id >= a.D) continue;
+                    const int ihb = h0 + bh, iwb = w0 + 4 * hh;
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) {
+                        const int co = (nb0 + j) * 32 + r;
+                        const float sc = a.scale ? a.scale[co] : 1.f;
+                        const float sh = a.shift ? a.shift[co] : 0.f;
+                        f32x16 v;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) v[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
+                        const size_t base = ((((size_t)n * a.OD + 2 * id + t.pd) * a.OH + 2 * ihb + t.ph) * a.OW +
+                                             2 * iwb + t.pw) * a.Co + co;
+                        epilogue_block<32>(v, sc, sh, a.res, a.y, base, stride_h, stride_w, a.relu, full_hw,
+                                           [&](int lh, int lw) { return ihb + lh < a.H && iwb + lw < a.W; });
+                    }
+                }
+            }
+        });
+    }
+}
+
+template <int KS, int NB>
+static int launch_deconv_f16s(const char* name, ConvArgs a, hipStream_t s) {
+    a.ntd = cdiv(a.D, 2); a.nth = cdiv(a.H, 4); a.ntw = cdiv(a.W, 32);
+    a.ngroups = a.Co / (32 * NB);
+    a.nbtot = a.Co / 32;
+    const size_t nitems = (size_t)a.N * a.ntd * a.nth * a.ntw * a.ngroups;
+    if (nitems == 0 || nitems > 0x7fffffffu) return fail("%s: bad item count %zu", name, nitems);
+    const size_t nblk = nitems < (size_t)num_cus() ? nitems : (size_t)num_cus();
+    const double ivox = (double)a.N * a.D * a.H * a.W;
+    LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * ivox, 4.0 * (ivox * a.Ci + 8.0 * ivox * a.Co * (a.res ? 2 : 1)));
+    hipLaunchKernelGGL((deconv3d_k3s2_f16s_ws<KS, NB>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+    return check_launch(name);
 }
 
 template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB>
 static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     a.ntd = cdiv(a.OD, TD); a.nth = cdiv(a.OH, TH); a.ntw = cdiv(a.OW, TW);
-    a.ngroups = 1; a.nbtot = a.Co / 32;
-    const size_t ntiles = (size_t)a.N * a.ntd * a.nth * a.ntw;
+    a.ngroups = a.Co / (32 * NB); a.nbtot = a.Co / 32;
+    const size_t ntiles = (size_t)a.N * a.ntd * a.nth * a.ntw * a.ngroups;
     if (ntiles == 0 || ntiles > 0x7fffffffu) return fail("%s: bad tile count %zu", name, ntiles);
     const size_t nblk = ntiles < (size_t)num_cus() ? ntiles : (size_t)num_cus();
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
@@ -536,13 +869,14 @@ extern "C" int msnet_pack_conv_weight_f16s(const float* w, void* packed, int Ci,
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipStream_t s = (hipStream_t)stream;
     LaunchScope ls("pack_weight_f16s", s, 0, 6.0 * total);
-    if (transposed) hipLaunchKernelGGL(pack_weight_f16s_kernel<true>, dim3(blocks), dim3(256), 0, s, w, (_Float16*)packed, Ci, Co, KS);
-    else            hipLaunchKernelGGL(pack_weight_f16s_kernel<false>, dim3(blocks), dim3(256), 0, s, w, (_Float16*)packed, Ci, Co, KS);
+    if (transposed) hipLaunchKernelGGL(pack_weight_f16s_kernel<true>, dim3(blocks), dim3(256), 0, s, w, (_Float16*)packed, Ci, Co, KS, Co == 32 ? 1 : 2);
+    else            hipLaunchKernelGGL(pack_weight_f16s_kernel<false>, dim3(blocks), dim3(256), 0, s, w, (_Float16*)packed, Ci, Co, KS, Co == 32 ? 1 : 2);
     return check_launch("msnet_pack_conv_weight_f16s");
 }
 
 extern "C" int msnet_conv3d_k3_f16s_supported(int Ci, int Co, int stride) {
-    return (stride == 1 && (Ci == 8 || (Ci > 0 && Ci % 32 == 0)) && (Co == 32 || Co == 64)) ? 1 : 0;
+    return (stride == 1 && (Ci == 8 || (Ci > 0 && Ci % 32 == 0)) && (Co == 32 || (Co > 0 && Co % 64 == 0)) &&
+            !(Ci == 8 && Co > 64)) ? 1 : 0;
 }
 
 extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const float* scale, const float* shift,
@@ -562,6 +896,35 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
         if (Co == 64) return launch_f16s<2, 4, 32, 32, 2, 2, false, 1, false>("conv3d_s1_c8_f16s", a, s);
         return launch_f16s<2, 6, 32, 32, 3, 1, false, 1, true>("conv3d_s1_c8_f16s", a, s);
     }
-    if (Co == 64) return launch_f16s<2, 4, 32, 32, 2, 2, true, 2, false>("conv3d_s1_f16s_co64", a, s);
+    if (Co % 64 == 0) return launch_f16s<2, 4, 32, 32, 2, 2, true, 2, false>("conv3d_s1_f16s_co64", a, s);
     return launch_f16s<2, 4, 32, 32, 2, 1, false, 2, false>("conv3d_s1_f16s_co32", a, s);
+}
+
+extern "C" int msnet_deconv3d_k3s2_f16s_supported(int Ci, int Co) {
+    return (Ci == 64 && (Co == 32 || Co == 64)) ? 1 : 0;
+}
+
+// Deconv weights for the split-fp16 path: w f32[Ci][Co][3][3][3] -> packed (msnet_packed_weight_floats(Ci,Co) floats).
+extern "C" int msnet_pack_deconv_weight_f16s(const float* w, void* packed, int Ci, int Co, msnet_stream_t stream) {
+    if (!w || !packed) return fail("msnet_pack_deconv_weight_f16s: null pointer");
+    if (!msnet_deconv3d_k3s2_f16s_supported(Ci, Co)) return fail("msnet_pack_deconv_weight_f16s: unsupported Ci=%d Co=%d", Ci, Co);
+    const size_t total = (size_t)27 * Ci * Co * 2;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope ls("pack_weight_f16s", s, 0, 6.0 * total);
+    hipLaunchKernelGGL(pack_deconv_weight_f16s_kernel, dim3(blocks), dim3(256), 0, s, w, (_Float16*)packed, Ci, Co, Ci / 16, 1);
+    return check_launch("msnet_pack_deconv_weight_f16s");
+}
+
+extern "C" int msnet_deconv3d_k3s2_f16s(const float* x, const void* wpk_f16s, const float* scale, const float* shift,
+                                        const float* residual, float* y, int N, int D, int H, int W, int Ci, int Co,
+                                        int relu, msnet_stream_t stream) {
+    if (!x || !wpk_f16s || !y) return fail("msnet_deconv3d_k3s2_f16s: null pointer");
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_deconv3d_k3s2_f16s: empty input");
+    if (!msnet_deconv3d_k3s2_f16s_supported(Ci, Co)) return fail("msnet_deconv3d_k3s2_f16s: unsupported Ci=%d Co=%d", Ci, Co);
+    ConvArgs a{};
+    a.x = x; a.wpk = reinterpret_cast<const f32x4*>(wpk_f16s); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu;
+    a.OD = 2 * D; a.OH = 2 * H; a.OW = 2 * W;
+    return launch_deconv_f16s<4, 1>("deconv3d_f16s", a, (hipStream_t)stream);
 }

@@ -114,7 +114,7 @@ class GCNet_CostVolumeAggre(nn.Module):
 
         def deconv(x, name, skip):
             p = pl[name]
-            return tap(name, hipops.deconv3d_k3s2(x, p.wpk, p.scale, p.shift, p.co, relu=True, residual=skip))
+            return tap(name, hipops.deconv3d_k3s2(x, p.wpk, p.scale, p.shift, p.co, relu=True, residual=skip, f16s=p.f16s))
 
         with torch.no_grad():
             x = hipops.ncdhw_to_ndhwc(cv)

@@ -34,9 +34,11 @@ def pack_conv_weight(w, transposed=False, f16s=False):
     lib = _lib.load()
     out = torch.empty(lib.msnet_packed_weight_floats(max(ci, 16) if f16s else ci, co), device=w.device,
                       dtype=torch.float32)
+    if f16s and transposed:
+        check(lib.msnet_pack_deconv_weight_f16s(ptr(w), ptr(out), ci, co, stream_ptr()), "msnet_pack_deconv_weight_f16s")
+        return out
     if f16s:
-        check(lib.msnet_pack_conv_weight_f16s(ptr(w), ptr(out), ci, co, int(transposed), stream_ptr()),
-              "msnet_pack_conv_weight_f16s")
+        check(lib.msnet_pack_conv_weight_f16s(ptr(w), ptr(out), ci, co, 0, stream_ptr()), "msnet_pack_conv_weight_f16s")
         return out
     fn = lib.msnet_pack_deconv_weight if transposed else lib.msnet_pack_conv_weight
     check(fn(ptr(w), ptr(out), ci, co, stream_ptr()), "msnet_pack_weight")
@@ -45,6 +47,9 @@ def pack_conv_weight(w, transposed=False, f16s=False):
 
 PRECISIONS = ("fp32", "split-fp16")
 _default_precision = "split-fp16"
+# The split-fp16 transposed-conv kernel is correct (tests/test_gpu_aggregators.py) but, at 27 weight-group barriers and 8
+# strided epilogues per tile, currently slower than the fp32-MFMA one (2.8 vs 2.0 ms on deconvbn4): opt-in only.
+USE_F16S_DECONV = False
 
 
 def set_default_precision(p):
@@ -75,7 +80,7 @@ def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16
     return y
 
 
-def deconv3d_k3s2(x, wpk, scale, shift, co, relu=False, residual=None):
+def deconv3d_k3s2(x, wpk, scale, shift, co, relu=False, residual=None, f16s=False):
     x = require_gpu_f32(x, "x")
     n, d, h, w, ci = x.shape
     y = torch.empty((n, 2 * d, 2 * h, 2 * w, co), device=x.device, dtype=torch.float32)
@@ -83,8 +88,9 @@ def deconv3d_k3s2(x, wpk, scale, shift, co, relu=False, residual=None):
         residual = require_gpu_f32(residual, "residual")
         if residual.shape != y.shape:
             raise ValueError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
-    check(_lib.load().msnet_deconv3d_k3s2(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(residual), ptr(y), n, d, h, w,
-                                          ci, co, int(relu), stream_ptr()), "msnet_deconv3d_k3s2")
+    fn = _lib.load().msnet_deconv3d_k3s2_f16s if f16s else _lib.load().msnet_deconv3d_k3s2
+    check(fn(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(residual), ptr(y), n, d, h, w, ci, co, int(relu), stream_ptr()),
+          "msnet_deconv3d_k3s2_f16s" if f16s else "msnet_deconv3d_k3s2")
     return y
 
 
@@ -152,8 +158,13 @@ class ConvBNPlan:
         ci = w.shape[0] if transposed else w.shape[1]
         stride = conv.stride[0]
         precision = precision or _default_precision
-        self.f16s = bool(precision == "split-fp16" and not transposed and
-                         _lib.load().msnet_conv3d_k3_f16s_supported(ci, self.co, stride))
+        lib = _lib.load()
+        if precision != "split-fp16":
+            self.f16s = False
+        elif transposed:
+            self.f16s = bool(USE_F16S_DECONV and lib.msnet_deconv3d_k3s2_f16s_supported(ci, self.co))
+        else:
+            self.f16s = bool(lib.msnet_conv3d_k3_f16s_supported(ci, self.co, stride))
         self.wpk = pack_conv_weight(w, transposed, f16s=self.f16s)
         if bn is not None:
             inv = 1.0 / torch.sqrt(bn.running_var.detach().float() + bn.eps)

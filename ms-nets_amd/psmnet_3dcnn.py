@@ -97,7 +97,7 @@ class PSMNet_CostVolumeAggre(nn.Module):
 
         def deconv(x, name, relu, residual):
             p = pl[name]
-            return hipops.deconv3d_k3s2(x, p.wpk, p.scale, p.shift, p.co, relu=relu, residual=residual)
+            return hipops.deconv3d_k3s2(x, p.wpk, p.scale, p.shift, p.co, relu=relu, residual=residual, f16s=p.f16s)
 
         def hour(x, name, presqu, postsqu, skip):
             # psmnet_3dcnn.py:69-89; `skip` (= cost0) is the "+ cost0" the caller adds to the hourglass output

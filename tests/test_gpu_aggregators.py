@@ -67,6 +67,8 @@ F16S_CASES = [
     (64, 64, (1, 4, 10, 24), True, True),
     (64, 32, (1, 4, 8, 48), False, False),
     (128, 64, (1, 3, 5, 9), True, False),
+    (128, 128, (1, 3, 5, 9), True, False),
+    (64, 128, (1, 4, 6, 33), True, True),
 ]
 
 
@@ -149,6 +151,32 @@ def test_deconv3d_layer(gpu, ci, co, dims, relu, use_res):
     y = hipops.deconv3d_k3s2(_cl(x), wpk, scale.cuda(), shift.cuda(), co, relu=relu, residual=_cl(res) if use_res else None)
     assert tuple(_nc(y).shape) == tuple(ref.shape)
     assert _rel(_nc(y), ref) < 2e-5
+
+
+@pytest.mark.parametrize("ci,co,dims,relu,use_res", [(64, 32, (1, 4, 9, 17), True, True), (64, 32, (2, 3, 4, 32), False, True),
+                                                   (64, 64, (1, 4, 6, 20), True, True), (64, 64, (1, 3, 5, 33), True, False)])
+def test_deconv3d_layer_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res):
+    from msnets_amd import hipops
+    assert hiplib.msnet_deconv3d_k3s2_f16s_supported(ci, co) == 1
+    g = torch.Generator().manual_seed(ci * 13 + co)
+    n, d, h, w = dims
+    x = torch.randn((n, ci, d, h, w), generator=g) * 3
+    wt = torch.randn((ci, co, 3, 3, 3), generator=g) * (2.0 / (27 * ci)) ** 0.5
+    scale = torch.rand(co, generator=g) + 0.5
+    shift = torch.randn(co, generator=g) * 0.1
+    ref = F.conv_transpose3d(x.double(), wt.double(), None, stride=2, padding=1, output_padding=1)
+    ref = ref * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    wpk = hipops.pack_conv_weight(wt.cuda(), transposed=True, f16s=True)
+    y = hipops.deconv3d_k3s2(_cl(x), wpk, scale.cuda(), shift.cuda(), co, relu=relu, residual=_cl(res) if use_res else None,
+                             f16s=True)
+    err = _rel(_nc(y).double(), ref)
+    print("split-fp16 deconv %d->%d rel err %.2e" % (ci, co, err))
+    assert err < 5e-6
 
 
 @pytest.mark.parametrize("dims,use_add", [((1, 5, 9, 33), False), ((2, 4, 8, 40), True), ((1, 1, 3, 5), False)])
@@ -250,6 +278,40 @@ def test_golden_end_to_end(gpu, name, precision):
         if key.startswith("tap_") and key[4:] in taps_hip:
             s, _ = recipes.sample(taps_hip[key[4:]].cpu())
             assert np.abs(s - gold[key]).max() <= 1e-4 * max(1.0, float(np.abs(gold[key]).max())), key
+
+
+@pytest.mark.parametrize("model_name,in_shape,maxdisp", [("gcnet", (1, 8, 96, 272, 480), 192),
+                                                         ("psmnet", (1, 64, 48, 136, 240), 192)])
+def test_full_benchmark_shape_matches_oracle(gpu, model_name, in_shape, maxdisp):
+    """BASELINE.json configs #2 / #3 at full size (960x544, D=192): HIP (default split-fp16 precision) vs the CPU oracle
+    on the same seeded weights and a random volume; also a size-independent property (disparity inside [0, D-1])."""
+    case = dict(model=model_name, seed=21, maxdisp=maxdisp, in_shape=in_shape)
+    model = recipes.build_case(case, *_our_classes())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = recipes.make_input(in_shape, 21)
+    got = model.cuda()(x.cuda()).cpu()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    with torch.no_grad():
+        if model_name == "gcnet":
+            ref = oracle.gcnet_forward(sd, x, maxdisp)
+        else:
+            ref = oracle.psmnet_forward(sd, x, maxdisp, recipes.out_hw(case))
+    err = float((got - ref).abs().max())
+    print("%s full size: max|disp - oracle| = %.3e, range %.2f..%.2f" % (model_name, err, float(ref.min()), float(ref.max())))
+    assert got.shape == ref.shape == (1, 544, 960)
+    assert float(got.min()) >= 0 and float(got.max()) <= maxdisp - 1
+    if err > DISP_TOL:
+        # With these random-init weights the 28-layer PSMNet at D=192 has a sharply peaked softmax and the fp32
+        # reference itself sits ~2e-2 from an fp64 evaluation of the same network (DESIGN.md section 5): the gate becomes
+        # "no further from exact arithmetic than the fp32 reference is".
+        with torch.no_grad():
+            sd64 = {k: v.double() for k, v in sd.items()}
+            ref64 = (oracle.gcnet_forward(sd64, x.double(), maxdisp) if model_name == "gcnet" else
+                     oracle.psmnet_forward(sd64, x.double(), maxdisp, recipes.out_hw(case))).float()
+        noise = float((ref - ref64).abs().max())
+        ours = float((got - ref64).abs().max())
+        print("%s full size: fp32 oracle vs fp64 = %.3e, HIP vs fp64 = %.3e" % (model_name, noise, ours))
+        assert ours <= noise + DISP_TOL
 
 
 def test_psmnet_all_heads(gpu):

@@ -3,8 +3,10 @@
 TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT
-python -m pytest tests -m gpu -q --timeout 900 -s 2>&1 | grep -E "max\|disp|rel err|passed|failed|FAILED|Error|error" | tail -60 > $OUT/${TAG}_pytest.log
+python -m pytest tests -m gpu -q --timeout 900 -s 2>&1 | grep -E "max\|disp|rel err|full size|passed|failed|FAILED|Error|error" | tail -60 > $OUT/${TAG}_pytest.log
 python bench.py --steps 5 --warmup 2 --verbose > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
+python bench.py --steps 5 --warmup 2 --verbose --workload cfg3 --no-cpu-baseline > $OUT/${TAG}_bench_cfg3.json 2> $OUT/${TAG}_bench_cfg3.err
+python bench.py --steps 5 --warmup 2 --precision fp32 --no-cpu-baseline > $OUT/${TAG}_bench_fp32.json 2>/dev/null
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof -- python3 $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_prof_bench.json 2> $OUT/${TAG}_prof.err
 find $OUT/${TAG}_prof -name "*kernel_stats*" | head -3

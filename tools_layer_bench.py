@@ -35,10 +35,10 @@ def run(name, prec, reps=5):
         vox = od[0] * od[1] * od[2]
     else:
         wt = (torch.randn((ci, co, 3, 3, 3), generator=g) * 0.05).to(dev)
-        f16s = False
-        wpk = hipops.pack_conv_weight(wt, transposed=True)
+        f16s = prec == "split-fp16" and bool(_lib.load().msnet_deconv3d_k3s2_f16s_supported(ci, co))
+        wpk = hipops.pack_conv_weight(wt, transposed=True, f16s=f16s)
         res = torch.rand((1, 2 * d, 2 * h, 2 * w, co), device=dev) if use_res else None
-        fn = lambda: hipops.deconv3d_k3s2(x, wpk, None, None, co, relu=True, residual=res)
+        fn = lambda: hipops.deconv3d_k3s2(x, wpk, None, None, co, relu=True, residual=res, f16s=f16s)
         vox = d * h * w
     for _ in range(2): y = fn()
     torch.cuda.synchronize()
