@@ -1,6 +1,8 @@
 """Full-size PSMNet / GCNet: HIP (both precisions) vs the fp32 oracle and an fp64 evaluation of the same network."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden"))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT_ = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT_); sys.path.insert(0, os.path.join(ROOT_, "tests", "golden"))
 import torch, recipes
 import msnets_amd
 from msnets_amd import hipops

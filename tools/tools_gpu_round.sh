@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU-box round: parity tests, verbose bench, rocprofv3 kernel stats.  Usage: gpurun -- bash tools_gpu_round.sh TAG
+# One GPU-box round: parity tests, verbose bench, rocprofv3 kernel stats.  Usage: gpurun -- bash tools/tools_gpu_round.sh TAG
 TAG=${1:-r01}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 mkdir -p $OUT

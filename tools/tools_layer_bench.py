@@ -1,6 +1,7 @@
 """Times single conv layers at benchmark shapes (HIP events), for kernel A/B work.
    python tools_layer_bench.py [name ...]      MSNET_HIP_LIB=<variant.so> selects another build."""
 import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch
 import msnets_amd

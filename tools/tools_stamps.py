@@ -1,5 +1,6 @@
 import sys, os, ctypes
-os.environ["MSNET_HIP_LIB"] = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ms-nets_amd", "lib_EXP_STAMP.so")
+os.environ["MSNET_HIP_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ms-nets_amd", "lib_EXP_STAMP.so")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import torch, tools_layer_bench as T
 from msnets_amd import _lib
