@@ -112,9 +112,9 @@ int msnet_conv3d_k3(const float* x, const float* wpk, const float* scale, const 
 /* Split-fp16 fast path of msnet_conv3d_k3 (same contract, fp32 tensors in HBM): every operand is used as
  * hi + lo*2^-11 (two fp16 halves, 22 significand bits) and each product costs three fp16 MFMAs
  * (ms-nets_amd/csrc/conv3d_f16s.hip).  wpk_f16s comes from msnet_pack_conv_weight_f16s (same byte count as the
- * fp32 packing: msnet_packed_weight_floats(Ci,Co) floats); `transposed` selects the ConvTranspose3d weight layout.
+ * fp32 packing: msnet_packed_weight_floats(max(Ci,16),Co) floats) for the same (Ci, Co, stride) it will be used with.
  * msnet_conv3d_k3_f16s_supported() tells whether a (Ci, Co, stride) has a split-fp16 kernel (else use msnet_conv3d_k3). */
-int msnet_pack_conv_weight_f16s(const float* w, void* packed, int Ci, int Co, int transposed, msnet_stream_t stream);
+int msnet_pack_conv_weight_f16s(const float* w, void* packed, int Ci, int Co, int stride, msnet_stream_t stream);
 int msnet_conv3d_k3_f16s_supported(int Ci, int Co, int stride);
 int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const float* scale, const float* shift,
                          const float* residual, float* y, int N, int D, int H, int W, int Ci, int Co,

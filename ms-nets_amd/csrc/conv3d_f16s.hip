@@ -111,11 +111,12 @@ __global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* _
 // KS = 16-channel K-steps per staged chunk: 2 (32-channel chunks) or 1 (the 8-channel first layer, zero-padded to 16).
 // RESB = true: all 27 taps of the (single-chunk) weight tensor stay resident in LDS for the whole kernel -- used when
 //               they fit beside the tile (the 8-channel layer: 54 KB): no weight streaming, 2 barriers per item instead of 10.
-template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB>
+// STRIDE = 1 or 2 (stride 2: the input tile is (2T+1)^3, so it is staged 16 channels at a time, KS = 1).
+template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB, int STRIDE>
 __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     constexpr int CC = 16 * KS;
     constexpr int BH = 32 / BW;
-    constexpr int ID = TD + 2, IH = TH + 2, IW = TW + 2;
+    constexpr int ID = (TD - 1) * STRIDE + 3, IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
     constexpr int HB = 2 * CC;                          // bytes of the hi (or lo) half of a voxel record
     constexpr int RB = SWZ ? 2 * HB : 2 * HB + 16;      // bytes per voxel record in LDS (hi + lo [+ 16 pad])
     static_assert(!SWZ || KS == 2, "the swizzle is written for 128-byte records");
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         // for the lanes whose offset is forced out of range = conv zero padding / partial last slot).
         constexpr int PSLOT = IH * IW * V;              // float4 per plane
         constexpr int PL = (PSLOT + 255) / 256;
-        static_assert(ID == 4, "plane schedule below assumes TD == 2");
+        static_assert(TD == 2 && (ID == 4 || ID == 5), "plane schedule below assumes TD == 2 (input planes d*S + kd)");
         f32x4 av[ID][PL];
         unsigned goff_[PL];                             // global byte offset of the slot from the plane tile origin
         int ihw_[PL];                                   // (ih << 8) | iw, or -1 for a slot past the plane's end
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         }
         // LDS offset of this thread's slot u in plane pl: voxel = pl*IH*IW + u*(256/V) + lt/V, channel quad c4 = lt % V.
         // The swizzle term (voxel>>1)&7 does not depend on u (256/V is a multiple of 16), only on the plane.
-        static_assert((IH * IW) % 2 == 0 && (256 / V) % 16 == 0, "per-plane swizzle below");
+        static_assert(!SWZ || ((IH * IW) % 2 == 0 && (256 / V) % 16 == 0), "per-plane swizzle below");
         int lhi_[ID];                                   // offset of the hi half for u = 0
 #pragma unroll
         for (int pl = 0; pl < ID; ++pl) {
@@ -214,22 +215,23 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         };
         // request slots [u0, u1) of plane pl of the tile at c
         auto issue_a = [&](const Coord& c, int pl, int u0, int u1) {
-            const int gd = c.od0 - 1 + pl;
+            const int gd = c.od0 * STRIDE - 1 + pl;
+            const int ih0 = c.oh0 * STRIDE - 1, iw0 = c.ow0 * STRIDE - 1;      // input origin of the tile
             const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<float*>(a.x) + (size_t)c.n * (sample_bytes / 4), 0, (int)sample_bytes, 0x00020000);
             // byte offset of voxel (gd, oh0-1, ow0-1), channel chunk*CC, inside the sample (may wrap below zero; the
             // in-range lanes add a positive goff_ that brings it back -- unsigned arithmetic)
             const unsigned base =
-                (unsigned)((((long)gd * a.H + (c.oh0 - 1)) * a.W + (c.ow0 - 1)) * a.Ci + c.chunk * CC) * 4u;
+                (unsigned)((((long)gd * a.H + ih0) * a.W + iw0) * a.Ci + c.chunk * CC) * 4u;
             static_assert(PL * 256 >= PSLOT, "slots cover the plane");
             const bool plane_ok = (unsigned)gd < (unsigned)a.D;
-            const bool interior = c.oh0 >= 1 && c.oh0 + TH + 1 <= a.H && c.ow0 >= 1 && c.ow0 + TW + 1 <= a.W;
+            const bool interior = ih0 >= 0 && ih0 + IH <= a.H && iw0 >= 0 && iw0 + IW <= a.W;
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
                 if (u < u0 || u >= u1) continue;
                 bool ok = ihw_[u] >= 0;
                 if (!interior) {
-                    const int gh = c.oh0 - 1 + (ihw_[u] >> 8), gw = c.ow0 - 1 + (ihw_[u] & 255);
+                    const int gh = ih0 + (ihw_[u] >> 8), gw = iw0 + (ihw_[u] & 255);
                     ok = ok && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
                 }
                 const unsigned voff = (ok && plane_ok) ? base + goff_[u] : 0xffffffffu;
@@ -339,6 +341,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
 #ifndef EXP_NO_A_STAGE
             if (!early) { write_a(0, 0, PL); write_a(1, 0, PL); }
             write_a(2, 0, PL); write_a(3, 0, PL);
+            if constexpr (ID > 4) write_a(4, 0, PL);
 #endif
             MSNET_WRITE_B(k0, bw0);
             MSNET_ISSUE_B(k0 + 3, bw0);
@@ -358,6 +361,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
             MSNET_GROUP(1, bw2)
 #ifndef EXP_NO_A_STAGE
             if (more) issue_a(nx, 3, 0, PL);
+            if constexpr (ID > 4) { if (more) issue_a(nx, 4, 0, PL); }
 #endif
             MSNET_GROUP(2, bw0)                         // g_2 passed: kd = 0 groups done, plane 0 is dead
 #ifndef EXP_NO_A_STAGE
@@ -397,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         const int mb = wm * MB + i;
         const int bw_ = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
         const int lh = bh * BH + r / BW, lw = bw_ * BW + r % BW;
-        vox0[i] = (bd * IH + lh) * IW + lw;
+        vox0[i] = (bd * STRIDE * IH + lh * STRIDE) * IW + lw * STRIDE;
     }
     const int stride_w = a.Co, stride_h = a.OW * a.Co;
 
@@ -834,7 +838,7 @@ static int launch_deconv_f16s(const char* name, ConvArgs a, hipStream_t s) {
     return check_launch(name);
 }
 
-template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB>
+template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB, int STRIDE = 1>
 static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     a.ntd = cdiv(a.OD, TD); a.nth = cdiv(a.OH, TH); a.ntw = cdiv(a.OW, TW);
     a.ngroups = a.Co / (32 * NB); a.nbtot = a.Co / 32;
@@ -844,7 +848,7 @@ static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
                    4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB, SWZ, KS, RESB>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB, SWZ, KS, RESB, STRIDE>), dim3((unsigned)nblk), dim3(512), 0, s, a);
     return check_launch(name);
 }
 
@@ -858,23 +862,26 @@ extern "C" int msnet_debug_read_stamps(unsigned long long* host) {
 }
 #endif
 
+extern "C" int msnet_conv3d_k3_f16s_supported(int Ci, int Co, int stride);
+
 // Split-fp16 packed size: 27 * max(Ci,16) * Co floats (2 halves per weight; Ci = 8 is zero-padded to 16 channels).
-extern "C" int msnet_pack_conv_weight_f16s(const float* w, void* packed, int Ci, int Co, int transposed,
+extern "C" int msnet_pack_conv_weight_f16s(const float* w, void* packed, int Ci, int Co, int stride,
                                            msnet_stream_t stream) {
     if (!w || !packed) return fail("msnet_pack_conv_weight_f16s: null pointer");
-    if (!(Ci == 8 || (Ci > 0 && Ci % 32 == 0))) return fail("msnet_pack_conv_weight_f16s: Ci=%d must be 8 or a multiple of 32", Ci);
-    const int KS = Ci == 8 ? 1 : 2;
+    if (!msnet_conv3d_k3_f16s_supported(Ci, Co, stride))
+        return fail("msnet_pack_conv_weight_f16s: unsupported Ci=%d Co=%d stride=%d", Ci, Co, stride);
+    const int KS = (Ci == 8 || stride == 2) ? 1 : 2;    // 16-channel K-steps per staged chunk
     if (Co <= 0 || Co % 32 != 0) return fail("msnet_pack_conv_weight_f16s: Co=%d must be a positive multiple of 32", Co);
     const size_t total = (size_t)27 * (Ci < 16 ? 16 : Ci) * Co * 2;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipStream_t s = (hipStream_t)stream;
     LaunchScope ls("pack_weight_f16s", s, 0, 6.0 * total);
-    if (transposed) hipLaunchKernelGGL(pack_weight_f16s_kernel<true>, dim3(blocks), dim3(256), 0, s, w, (_Float16*)packed, Ci, Co, KS, Co == 32 ? 1 : 2);
-    else            hipLaunchKernelGGL(pack_weight_f16s_kernel<false>, dim3(blocks), dim3(256), 0, s, w, (_Float16*)packed, Ci, Co, KS, Co == 32 ? 1 : 2);
+    hipLaunchKernelGGL(pack_weight_f16s_kernel<false>, dim3(blocks), dim3(256), 0, s, w, (_Float16*)packed, Ci, Co, KS, Co == 32 ? 1 : 2);
     return check_launch("msnet_pack_conv_weight_f16s");
 }
 
 extern "C" int msnet_conv3d_k3_f16s_supported(int Ci, int Co, int stride) {
+    if (stride == 2) return (Ci > 0 && Ci % 16 == 0 && Co > 0 && Co % 64 == 0) ? 1 : 0;
     return (stride == 1 && (Ci == 8 || (Ci > 0 && Ci % 32 == 0)) && (Co == 32 || (Co > 0 && Co % 64 == 0)) &&
             !(Ci == 8 && Co > 64)) ? 1 : 0;
 }
@@ -889,8 +896,10 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
     ConvArgs a{};
     a.x = x; a.wpk = reinterpret_cast<const f32x4*>(wpk_f16s); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu;
-    a.OD = D; a.OH = H; a.OW = W;
+    a.OD = (D - 1) / stride + 1; a.OH = (H - 1) / stride + 1; a.OW = (W - 1) / stride + 1;
     hipStream_t s = (hipStream_t)stream;
+    if (stride == 2)   // 2x2x32 output tile <- 5x5x65 input voxels x 16 channels (130 KB); 4 M-blocks, one per MFMA wave
+        return launch_f16s<2, 2, 32, 32, 1, 2, false, 1, false, 2>("conv3d_s2_f16s", a, s);
     //                                    TD TH TW  BW MB NB
     if (Ci == 8) {
         if (Co == 64) return launch_f16s<2, 4, 32, 32, 2, 2, false, 1, false>("conv3d_s1_c8_f16s", a, s);

@@ -24,7 +24,7 @@ def ndhwc_to_ncdhw(x):
     return y
 
 
-def pack_conv_weight(w, transposed=False, f16s=False):
+def pack_conv_weight(w, transposed=False, f16s=False, stride=1):
     """nn.Conv3d.weight [Co,Ci,3,3,3] (or ConvTranspose3d.weight [Ci,Co,3,3,3]) -> MFMA-ordered buffer
     (fp32 lane order, or the split-fp16 hi/lo image when f16s)."""
     w = require_gpu_f32(w, "weight")
@@ -38,7 +38,8 @@ def pack_conv_weight(w, transposed=False, f16s=False):
         check(lib.msnet_pack_deconv_weight_f16s(ptr(w), ptr(out), ci, co, stream_ptr()), "msnet_pack_deconv_weight_f16s")
         return out
     if f16s:
-        check(lib.msnet_pack_conv_weight_f16s(ptr(w), ptr(out), ci, co, 0, stream_ptr()), "msnet_pack_conv_weight_f16s")
+        check(lib.msnet_pack_conv_weight_f16s(ptr(w), ptr(out), ci, co, int(stride), stream_ptr()),
+              "msnet_pack_conv_weight_f16s")
         return out
     fn = lib.msnet_pack_deconv_weight if transposed else lib.msnet_pack_conv_weight
     check(fn(ptr(w), ptr(out), ci, co, stream_ptr()), "msnet_pack_weight")
@@ -165,7 +166,7 @@ class ConvBNPlan:
             self.f16s = bool(USE_F16S_DECONV and lib.msnet_deconv3d_k3s2_f16s_supported(ci, self.co))
         else:
             self.f16s = bool(lib.msnet_conv3d_k3_f16s_supported(ci, self.co, stride))
-        self.wpk = pack_conv_weight(w, transposed, f16s=self.f16s)
+        self.wpk = pack_conv_weight(w, transposed, f16s=self.f16s, stride=stride)
         if bn is not None:
             inv = 1.0 / torch.sqrt(bn.running_var.detach().float() + bn.eps)
             self.scale = (bn.weight.detach().float() * inv).contiguous()

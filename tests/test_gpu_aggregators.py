@@ -72,6 +72,35 @@ F16S_CASES = [
 ]
 
 
+F16S_S2_CASES = [(32, 64, (1, 8, 12, 34), True, False), (64, 64, (1, 6, 9, 33), True, True), (64, 128, (1, 4, 6, 10), True, False),
+                 (32, 64, (2, 5, 7, 70), False, False)]
+
+
+@pytest.mark.parametrize("ci,co,dims,relu,use_res", F16S_S2_CASES)
+def test_conv3d_stride2_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res):
+    from msnets_amd import hipops
+    assert hiplib.msnet_conv3d_k3_f16s_supported(ci, co, 2) == 1
+    g = torch.Generator().manual_seed(ci * 7 + co)
+    n, d, h, w = dims
+    x = torch.randn((n, ci, d, h, w), generator=g) * 3
+    wt = torch.randn((co, ci, 3, 3, 3), generator=g) * (2.0 / (27 * ci)) ** 0.5
+    scale = torch.rand(co, generator=g) + 0.5
+    shift = torch.randn(co, generator=g) * 0.1
+    ref = F.conv3d(x.double(), wt.double(), None, stride=2, padding=1) * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    wpk = hipops.pack_conv_weight(wt.cuda(), f16s=True, stride=2)
+    y = hipops.conv3d_k3(_cl(x), wpk, scale.cuda(), shift.cuda(), co, stride=2, relu=relu,
+                         residual=_cl(res) if use_res else None, f16s=True)
+    assert tuple(_nc(y).shape) == tuple(ref.shape)
+    err = _rel(_nc(y).double(), ref)
+    print("split-fp16 s2 %d->%d rel err %.2e" % (ci, co, err))
+    assert err < 5e-6
+
+
 @pytest.mark.parametrize("ci,co,dims,relu,use_res", F16S_CASES)
 def test_conv3d_layer_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res):
     """Split-fp16 MFMA path: operands carry 22 bits, so a single layer agrees with the fp64 conv to ~1e-6

@@ -29,7 +29,7 @@ def run(name, prec, reps=5):
     if kind == "conv":
         wt = (torch.randn((co, ci, 3, 3, 3), generator=g) * 0.05).to(dev)
         f16s = prec == "split-fp16" and bool(_lib.load().msnet_conv3d_k3_f16s_supported(ci, co, stride))
-        wpk = hipops.pack_conv_weight(wt, f16s=f16s)
+        wpk = hipops.pack_conv_weight(wt, f16s=f16s, stride=stride)
         od = [(v - 1) // stride + 1 for v in (d, h, w)]
         res = torch.rand((1, *od, co), device=dev) if use_res else None
         fn = lambda: hipops.conv3d_k3(x, wpk, None, None, co, stride=stride, relu=True, residual=res, f16s=f16s)
