@@ -122,7 +122,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     static_assert(!SWZ || KS == 2, "the swizzle is written for 128-byte records");
     static_assert(BW == 32, "bank-conflict analysis assumes M-blocks of 32 consecutive voxels");
     constexpr int MW = TW / BW, MH = TH / BH;
-    constexpr int V = CC / 4;
+    constexpr int V = CC / 4;                           // float4 per voxel record half-row (incl. zero padding)
     constexpr int NPOS = ID * IH * IW;
     constexpr int GB = 3 * KS * NB * 2 * 1024;          // bytes of one weight group
     constexpr int PG = GB / 16;                         // 16-byte pieces per weight group
@@ -180,7 +180,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         // Per-slot constants (position inside a plane, global byte offset relative to the plane's tile origin, LDS
         // offsets) are computed once; per item a slot costs one add + one buffer load (hardware range check returns 0
         // for the lanes whose offset is forced out of range = conv zero padding / partial last slot).
-        constexpr int PSLOT = IH * IW * V;              // float4 per plane
+        // VR = float4 actually staged per voxel: the 8-channel first layer (RESB variant) only moves its 2 real quads;
+        // the padding channels of its LDS records are zeroed once below and never touched again.
+        constexpr int VR = RESB ? 2 : V;
+        constexpr int PSLOT = IH * IW * VR;             // float4 per plane
         constexpr int PL = (PSLOT + 255) / 256;
         static_assert(TD == 2 && (ID == 4 || ID == 5), "plane schedule below assumes TD == 2 (input planes d*S + kd)");
         f32x4 av[ID][PL];
@@ -189,19 +192,19 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
 #pragma unroll
         for (int u = 0; u < PL; ++u) {
             const int slot = u * 256 + lt;
-            const int pos = slot / V, c4 = slot % V;
+            const int pos = slot / VR, c4 = slot % VR;
             const int ih = pos / IW, iw = pos % IW;
-            const bool ok = slot < PSLOT && c4 * 4 < a.Ci;      // channels beyond Ci (first layer) are zero padding
+            const bool ok = slot < PSLOT && c4 * 4 < a.Ci;      // channels beyond Ci are zero padding
             goff_[u] = (unsigned)(((ih * a.W + iw) * a.Ci + c4 * 4) * 4);
             ihw_[u] = ok ? ((ih << 8) | iw) : -1;
         }
-        // LDS offset of this thread's slot u in plane pl: voxel = pl*IH*IW + u*(256/V) + lt/V, channel quad c4 = lt % V.
-        // The swizzle term (voxel>>1)&7 does not depend on u (256/V is a multiple of 16), only on the plane.
-        static_assert(!SWZ || ((IH * IW) % 2 == 0 && (256 / V) % 16 == 0), "per-plane swizzle below");
+        // LDS offset of this thread's slot u in plane pl: voxel = pl*IH*IW + u*(256/VR) + lt/VR, channel quad c4 = lt % VR.
+        // The swizzle term (voxel>>1)&7 does not depend on u (256/VR is a multiple of 16), only on the plane.
+        static_assert(!SWZ || ((IH * IW) % 2 == 0 && (256 / VR) % 16 == 0), "per-plane swizzle below");
         int lhi_[ID];                                   // offset of the hi half for u = 0
 #pragma unroll
         for (int pl = 0; pl < ID; ++pl) {
-            const int p0 = lt / V, c4 = lt % V;
+            const int p0 = lt / VR, c4 = lt % VR;
             const int sw = SWZ ? (((p0 >> 1) + pl * (IH * IW / 2)) & 7) : 0;
             lhi_[pl] = (pl * IH * IW + p0) * RB + (c4 & 1) * 8 + (((c4 >> 1) ^ sw) << 4);
         }
@@ -244,10 +247,10 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
                 if (u < u0 || u >= u1) continue;
-                if (u * 256 + lt < PSLOT) {             // padded channels are written too (as zeros)
+                if (u * 256 + lt < PSLOT) {
                     half4 hi, lo;
                     split4(av[pl][u], hi, lo);
-                    const int off = lhi_[pl] + u * (256 / V) * RB;
+                    const int off = lhi_[pl] + u * (256 / VR) * RB;
                     *reinterpret_cast<half4*>(lds + off) = hi;
                     *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ 64) : off + HB)) = lo;
                 }
@@ -295,6 +298,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
 #endif
 
         if constexpr (RESB) {
+            for (int p = lt * 16; p < NPOS * RB; p += 256 * 16)      // zero the records once (padding channels stay zero)
+                *reinterpret_cast<u32x4*>(lds + p) = u32x4{0u, 0u, 0u, 0u};
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             // weights: one pass, all 9 groups, before the first tile is published
             for (int k = 0; k < 9; ++k) {               // (RESB is only used with a single channel group and chunk)
                 const u32x4* src = wg + (size_t)k * PG;
