@@ -337,6 +337,229 @@ __global__ __launch_bounds__(256) void assemble_kernel(AssembleArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- fused features -----------------------
+// One kernel per matcher goes from the images (plus small per-pixel tables) straight to the two volume channels
+// it owns: thread = one cropped pixel, lanes along x (256-byte coalesced rows per d); raw cost for every d, min,
+// sequential likelihood sum, then the normalised cost and the likelihood.  The d-major raw-cost volumes over the
+// bordered image (4 x 56 MB written, read three times, plus the crop) never exist; only sadsob keeps its float32
+// integral image, whose sequential passes cannot be fused.  Arithmetic is the per-matcher kernels' arithmetic.
+struct FusedArgs {
+    const uint8_t* l; const uint8_t* r;
+    const uint32_t* lb; const uint32_t* rb;      // census bit images
+    const double* nal; const double* ncl; const double* nar; const double* ncr;   // NCC: window sum A and 1/sqrt term C
+    const float* ml; const float* mr;            // ZSAD window means
+    const float* integ;                          // sadsob integral images [nd][Hb+1][Wb+1]
+    float* out;
+    float sigma[4];
+    int Hb, Wb, nd, bh, bw, Hc, Wc;
+    int censw, nccw, sadw, sobelw, nwords;
+};
+
+// per-pixel tables: NCC (A, C) of both images and ZSAD means of both images, at window-centre coordinates
+__global__ void pixel_tables_kernel(FusedArgs a) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= a.Wb) return;
+    const int W = a.Wb, H = a.Hb;
+    const size_t c = (size_t)y * W + x;
+    {   // NCC
+        const int ws = a.nccw, wc = ws / 2, i = y - wc, j = x - wc;
+        double Al = 0, Cl = 0, Ar = 0, Cr = 0;
+        if (i >= 0 && j >= 0 && i < H - ws && j < W - ws) {
+            unsigned long long sl = 0, sr = 0, ql = 0, qr = 0;
+            for (int wh = 0; wh < ws; ++wh)
+                for (int ww = 0; ww < ws; ++ww) {
+                    const unsigned p = a.l[(i + wh) * W + j + ww], q = a.r[(i + wh) * W + j + ww];
+                    sl += p; sr += q; ql += p * p; qr += q * q;
+                }
+            const unsigned long long sq = (unsigned long long)(ws * ws);
+            Al = (double)sl; Ar = (double)sr;
+            Cl = 1.0 / sqrt((double)(sq * ql) - (double)sl * (double)sl);
+            Cr = 1.0 / sqrt((double)(sq * qr) - (double)sr * (double)sr);
+        }
+        const_cast<double*>(a.nal)[c] = Al;
+        const_cast<double*>(a.ncl)[c] = Cl; const_cast<double*>(a.nar)[c] = Ar; const_cast<double*>(a.ncr)[c] = Cr;
+    }
+    {   // ZSAD means
+        const int ws = a.sadw, wc = ws / 2, i = y - wc, j = x - wc;
+        float ml = 0.f, mr = 0.f;
+        if (i >= 0 && j >= 0 && i < H - ws && j < W - ws) {
+            ml = window_mean(a.l + i * W + j, W, ws);
+            mr = window_mean(a.r + i * W + j, W, ws);
+        }
+        const_cast<float*>(a.ml)[c] = ml; const_cast<float*>(a.mr)[c] = mr;
+    }
+}
+
+// Per-pixel cost generators.  WS > 0 fixes the window at compile time (the defaults 11/3/5/5): the loops unroll and
+// everything that does not depend on d (left window, left tables) stays in registers; WS == 0 takes the window from
+// the arguments.  `emit(d, c)` is called for d = 0..nd-1 in order.
+template <int WS, class F>
+__device__ __forceinline__ void census_costs(const FusedArgs& a, int yb, int xb, F emit) {
+    const int W = a.Wb, H = a.Hb, ws = WS > 0 ? WS : a.censw, wc = ws / 2, i = yb - wc, j = xb - wc;
+    constexpr int NW = WS > 0 ? (WS * WS + 31) / 32 : kCensusWords;
+    const int nwords = WS > 0 ? NW : a.nwords;
+    const bool ok = i >= 0 && j >= 0 && i < H - ws && j < W - ws;
+    uint32_t lw[NW];
+    const uint32_t* p = a.lb + ((size_t)yb * W + xb) * nwords;
+#pragma unroll
+    for (int k = 0; k < NW; ++k) lw[k] = (ok && k < nwords) ? p[k] : 0u;
+    for (int d = 0; d < a.nd; ++d) {
+        float c = kSentinel;
+        if (ok && j >= d) {
+            const uint32_t* q = a.rb + ((size_t)yb * W + xb - d) * nwords;
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < NW; ++k)
+                if (k < nwords) cnt += __popc(lw[k] ^ q[k]);
+            c = (float)cnt;
+        }
+        emit(d, c);
+    }
+}
+
+template <int WS, class F>
+__device__ __forceinline__ void ncc_costs(const FusedArgs& a, int yb, int xb, F emit) {
+    const int W = a.Wb, H = a.Hb, ws = WS > 0 ? WS : a.nccw, wc = ws / 2, i = yb - wc, j = xb - wc;
+    const bool ok = i >= 0 && j >= 0 && i < H - ws && j < W - ws;
+    const size_t cl = (size_t)yb * W + xb;
+    const double Cl = ok ? a.ncl[cl] : 0.0, Al = ok ? a.nal[cl] : 0.0;
+    const double sq = (double)(ws * ws);
+    constexpr int NL = WS > 0 ? WS * WS : 1;
+    unsigned lv[NL];
+    if (WS > 0) {
+#pragma unroll
+        for (int k = 0; k < NL; ++k) lv[k] = ok ? a.l[(i + k / (WS > 0 ? WS : 1)) * W + j + k % (WS > 0 ? WS : 1)] : 0u;
+    }
+    for (int d = 0; d < a.nd; ++d) {
+        float c = kSentinel;
+        if (ok && j >= d) {
+            const double Cr = a.ncr[cl - d];
+            if (!(isfinite(Cl) && isfinite(Cr))) {
+                c = 1.f;
+            } else {
+                unsigned long long LR = 0;
+                if (WS > 0) {
+                    unsigned acc = 0;      // WS*WS*255*255 < 2^32 for WS <= 16
+#pragma unroll
+                    for (int k = 0; k < NL; ++k)
+                        acc += lv[k] * (unsigned)a.r[(i + k / (WS > 0 ? WS : 1)) * W + j - d + k % (WS > 0 ? WS : 1)];
+                    LR = acc;
+                } else {
+                    for (int wh = 0; wh < ws; ++wh) {
+                        const uint8_t* lp = a.l + (i + wh) * W + j;
+                        const uint8_t* rp = a.r + (i + wh) * W + j - d;
+                        for (int ww = 0; ww < ws; ++ww) LR += (unsigned)lp[ww] * (unsigned)rp[ww];
+                    }
+                }
+                const double num = sq * (double)LR - Al * a.nar[cl - d];
+                double t = -num;
+                t = t * Cl;
+                t = t * Cr;
+                c = (float)t;
+            }
+        }
+        emit(d, c);
+    }
+}
+
+template <int WS, class F>
+__device__ __forceinline__ void sobel_costs(const FusedArgs& a, int yb, int xb, F emit) {
+    const int W = a.Wb, H = a.Hb, ws = WS > 0 ? WS : a.sobelw, wc = ws / 2, i = yb - wc, j = xb - wc;
+    const bool ok = i >= 0 && j >= 0 && i < H - ws && j < W - ws;
+    const size_t plane = (size_t)(H + 1) * (W + 1);
+    const float* t = a.integ + (size_t)(ok ? i : 0) * (W + 1) + (ok ? j : 0);
+    const float* b = t + (size_t)ws * (W + 1);
+    for (int d = 0; d < a.nd; ++d, t += plane, b += plane) {
+        float c = kSentinel;
+        if (ok && j >= d) {
+            float r = b[ws] - b[0];
+            r = r - t[ws];
+            r = r + t[0];
+            c = r;
+        }
+        emit(d, c);
+    }
+}
+
+template <int WS, class F>
+__device__ __forceinline__ void zsad_costs(const FusedArgs& a, int yb, int xb, F emit) {
+    const int W = a.Wb, H = a.Hb, ws = WS > 0 ? WS : a.sadw, wc = ws / 2, i = yb - wc, j = xb - wc;
+    const bool ok = i >= 0 && j >= 0 && i < H - ws && j < W - ws;
+    const size_t cl = (size_t)yb * W + xb;
+    const float ml = ok ? a.ml[cl] : 0.f;
+    constexpr int NL = WS > 0 ? WS * WS : 1;
+    constexpr int WD = WS > 0 ? WS : 1;
+    float lm[NL];                                       // (float)L - mean_L: first step of the reference's expression
+    if (WS > 0) {
+#pragma unroll
+        for (int k = 0; k < NL; ++k) lm[k] = ok ? (float)a.l[(i + k / WD) * W + j + k % WD] - ml : 0.f;
+    }
+    for (int d = 0; d < a.nd; ++d) {
+        float c = kSentinel;
+        if (ok && j >= d) {
+            const float mr = a.mr[cl - d];
+            const uint8_t* rp = a.r + i * W + j - d;
+            float acc = 0.f;
+            if (WS > 0) {
+#pragma unroll
+                for (int k = 0; k < NL; ++k) {
+                    float t = lm[k] - (float)rp[(k / WD) * W + k % WD];
+                    t = t + mr;
+                    acc = acc + fabsf(t);
+                }
+            } else {
+                const uint8_t* lp = a.l + i * W + j;
+                for (int wh = 0; wh < ws; ++wh)
+                    for (int ww = 0; ww < ws; ++ww) {
+                        float t = (float)lp[wh * W + ww] - ml;
+                        t = t - (float)rp[wh * W + ww];
+                        t = t + mr;
+                        acc = acc + fabsf(t);
+                    }
+            }
+            c = acc;
+        }
+        emit(d, c);
+    }
+}
+
+// The raw costs are parked in the cost channel's own output slots (written and re-read by the same thread, so they
+// stay in L2 and need no fence), then overwritten with the normalised cost in the last pass.
+template <int M, int WS>
+__global__ __launch_bounds__(256) void features_fused_kernel(FusedArgs a) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= a.Wc || y >= a.Hc) return;
+    const int yb = y + a.bh, xb = x + a.bw;
+    const size_t plane_out = (size_t)a.Hc * a.Wc;
+    float* o_cost = a.out + ((size_t)M * a.nd) * plane_out + (size_t)y * a.Wc + x;
+    float* o_aml = a.out + ((size_t)(4 + M) * a.nd) * plane_out + (size_t)y * a.Wc + x;
+    float m = kSentinel;
+    auto emit = [&](int d, float c) {
+        o_cost[d * plane_out] = c;
+        if (c < m) m = c;
+    };
+    if (M == 0) census_costs<WS>(a, yb, xb, emit);
+    else if (M == 1) ncc_costs<WS>(a, yb, xb, emit);
+    else if (M == 2) sobel_costs<WS>(a, yb, xb, emit);
+    else zsad_costs<WS>(a, yb, xb, emit);
+    const float sigma = a.sigma[M];
+    float den = 0.f;
+#pragma unroll 8
+    for (int d = 0; d < a.nd; ++d) den += aml_term(o_cost[d * plane_out], m, sigma);
+#pragma unroll 8
+    for (int d = 0; d < a.nd; ++d) {
+        const float c = o_cost[d * plane_out];
+        o_cost[d * plane_out] = normalise_cost(M, c);
+        o_aml[d * plane_out] = (m == kSentinel) ? 0.f : aml_term(c, m, sigma) / den;
+    }
+}
+
+template <int M, int WS>
+static void launch_features(const char* name, const FusedArgs& a, hipStream_t s) {
+    LaunchScope ls(name, s, 0, 4.0 * 2.0 * a.nd * (double)a.Hc * a.Wc);
+    hipLaunchKernelGGL((features_fused_kernel<M, WS>), dim3(cdiv(a.Wc, 64), cdiv(a.Hc, 4)), dim3(256), 0, s, a);
+}
+
 static inline int grid1d(size_t total, int cap = 16384) {
     const size_t b = (total + 255) / 256;
     return (int)(b < (size_t)cap ? (b ? b : 1) : cap);
@@ -487,13 +710,14 @@ extern "C" void msnet_volume_default_params(msnet_volume_params* p) {
     p->border_h = 10; p->border_w = 10;
 }
 
-// workspace carve (floats unless noted): raw[4] each nd*Hb*Wb | sobel L,R each Hb*Wb | integral nd*(Hb+1)*(Wb+1)
-// | census bit images 2*Hb*Wb*8 u32
+// workspace carve: sadsob integral nd*(Hb+1)*(Wb+1) f32 | sobel L,R 2*Hb*Wb f32 | ZSAD means 2*Hb*Wb f32 |
+// NCC tables 4*Hb*Wb f64 | census bit images 2*Hb*Wb*8 u32
 extern "C" size_t msnet_build_volume_workspace_bytes(int Hb, int Wb, int ndisp) {
     if (Hb <= 0 || Wb <= 0 || ndisp <= 0) return 0;
-    const size_t vol = (size_t)ndisp * Hb * Wb;
-    const size_t fl = 4 * vol + 2 * (size_t)Hb * Wb + (size_t)ndisp * (Hb + 1) * (Wb + 1) + 16 * (size_t)Hb * Wb;
-    return (fl * sizeof(float) + 255) & ~(size_t)255;
+    const size_t img = (size_t)Hb * Wb;
+    const size_t bytes = ((size_t)ndisp * (Hb + 1) * (Wb + 1) + 4 * img) * sizeof(float) + 4 * img * sizeof(double) +
+                         16 * img * sizeof(uint32_t) + 64;
+    return (bytes + 255) & ~(size_t)255;
 }
 
 extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int ndisp,
@@ -510,25 +734,44 @@ extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, in
     if (int e = check_img("msnet_build_volume", l, r, out, Hb, Wb, ndisp, p.sadw)) return e;
     if (int e = check_img("msnet_build_volume", l, r, out, Hb, Wb, ndisp, p.sobelw)) return e;
     hipStream_t s = (hipStream_t)stream;
-    const size_t vol = (size_t)ndisp * Hb * Wb, img = (size_t)Hb * Wb;
-    float* w = (float*)workspace;
-    float* raw_census = w; float* raw_ncc = w + vol; float* raw_sob = w + 2 * vol; float* raw_sad = w + 3 * vol;
-    float* sobl = w + 4 * vol; float* sobr = sobl + img;
-    float* integ = sobr + img;
-    uint32_t* bits = (uint32_t*)(integ + (size_t)ndisp * (Hb + 1) * (Wb + 1));
+    const size_t img = (size_t)Hb * Wb;
+    float* integ = (float*)workspace;
+    float* sobl = integ + (size_t)ndisp * (Hb + 1) * (Wb + 1);
+    float* sobr = sobl + img;
+    float* ml = sobr + img;
+    float* mr = ml + img;
+    double* tab = (double*)(((uintptr_t)(mr + img) + 15) & ~(uintptr_t)15);
+    uint32_t* bits = (uint32_t*)(tab + 4 * img);
+    const int nwords = (p.censw * p.censw + 31) / 32;
 
-    if (int e = census_impl(l, r, raw_census, bits, Hb, Wb, ndisp, p.censw, true, s)) return e;
-    if (int e = msnet_ncc(l, r, raw_ncc, Hb, Wb, ndisp, p.nccw, stream)) return e;
-    if (int e = msnet_zsad(l, r, raw_sad, Hb, Wb, ndisp, p.sadw, stream)) return e;
-    if (int e = msnet_sobel(l, sobl, Hb, Wb, stream)) return e;
-    if (int e = msnet_sobel(r, sobr, Hb, Wb, stream)) return e;
-    if (int e = sadsob_impl(sobl, sobr, raw_sob, integ, Hb, Wb, ndisp, p.sobelw, s)) return e;
-
-    AssembleArgs a;
-    a.raw[0] = raw_census; a.raw[1] = raw_ncc; a.raw[2] = raw_sob; a.raw[3] = raw_sad;
+    FusedArgs a{};
+    a.l = l; a.r = r; a.lb = bits; a.rb = bits + img * nwords;
+    a.nal = tab; a.ncl = tab + img; a.nar = tab + 2 * img; a.ncr = tab + 3 * img;
+    a.ml = ml; a.mr = mr; a.integ = integ; a.out = out;
     a.sigma[0] = p.cens_sigma; a.sigma[1] = p.ncc_sigma; a.sigma[2] = p.sad_sigma; a.sigma[3] = p.sad_sigma;
-    a.out = out; a.Hb = Hb; a.Wb = Wb; a.nd = ndisp; a.bh = p.border_h; a.bw = p.border_w; a.Hc = Hc; a.Wc = Wc;
-    LaunchScope ls("volume_assemble", s, 0, 4.0 * (8.0 * ndisp * Hc * Wc + 4.0 * vol));
-    hipLaunchKernelGGL(assemble_kernel, dim3(cdiv(Wc, 256), Hc, 4), dim3(256), 0, s, a);
+    a.Hb = Hb; a.Wb = Wb; a.nd = ndisp; a.bh = p.border_h; a.bw = p.border_w; a.Hc = Hc; a.Wc = Wc;
+    a.censw = p.censw; a.nccw = p.nccw; a.sadw = p.sadw; a.sobelw = p.sobelw; a.nwords = nwords;
+
+    dim3 g2(cdiv(Wb, 64), Hb);
+    {
+        LaunchScope ls("volume_prep", s, 0, 2.0 * img * (1 + 4.0 * nwords) + 48.0 * img);
+        hipLaunchKernelGGL(census_transform_kernel, g2, dim3(64), 0, s, l, const_cast<uint32_t*>(a.lb), Hb, Wb, p.censw, nwords);
+        hipLaunchKernelGGL(census_transform_kernel, g2, dim3(64), 0, s, r, const_cast<uint32_t*>(a.rb), Hb, Wb, p.censw, nwords);
+        hipLaunchKernelGGL(pixel_tables_kernel, g2, dim3(64), 0, s, a);
+        hipLaunchKernelGGL(sobel_kernel, g2, dim3(64), 0, s, l, sobl, Hb, Wb);
+        hipLaunchKernelGGL(sobel_kernel, g2, dim3(64), 0, s, r, sobr, Hb, Wb);
+    }
+    {
+        LaunchScope ls("sadsob_vertical", s, 0, 4.0 * ndisp * (double)(Hb + 1) * (Wb + 1));
+        hipLaunchKernelGGL(sadsob_vertical_kernel, dim3(cdiv(Wb + 1, 64), ndisp), dim3(64), 0, s, sobl, sobr, integ, Hb, Wb, ndisp);
+    }
+    {
+        LaunchScope ls("sadsob_horizontal", s, 0, 8.0 * ndisp * (double)(Hb + 1) * (Wb + 1));
+        hipLaunchKernelGGL(sadsob_horizontal_kernel, dim3(cdiv(Hb + 1, 64), ndisp), dim3(64), 0, s, integ, Hb, Wb, ndisp);
+    }
+    if (p.censw == 11) launch_features<0, 11>("features_census", a, s); else launch_features<0, 0>("features_census", a, s);
+    if (p.nccw == 3)   launch_features<1, 3>("features_ncc", a, s);     else launch_features<1, 0>("features_ncc", a, s);
+    if (p.sobelw == 5) launch_features<2, 5>("features_sobel", a, s);   else launch_features<2, 0>("features_sobel", a, s);
+    if (p.sadw == 5)   launch_features<3, 5>("features_zsad", a, s);    else launch_features<3, 0>("features_zsad", a, s);
     return check_launch("msnet_build_volume");
 }

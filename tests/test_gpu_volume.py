@@ -98,6 +98,18 @@ def test_fused_volume_build(gpu, H, W, nd, seed, kind):
     assert got.min() >= 0 and got.max() <= 1
 
 
+def test_fused_volume_build_other_windows(gpu):
+    """Non-default window sizes take the run-time-window kernels."""
+    from msnets_amd import cbmv_generator as cg
+    l, r = _pair(64, 90, 12, 11, "random")
+    c, n, so, sa = O.get_costs(l, r, 12, 9, 5, 3, 7, 10, 10, 10)
+    ref = O.extract_features_left(c, n, so, sa, 128.0, 0.02, 20000.0, 20000.0)
+    got = cg.build_ms_volume(l, r, 12, params=dict(censw=9, nccw=5, sadw=3, sobelw=7))
+    for ch, nm in enumerate(["census", "ncc", "sobel", "sad"]):
+        _bitexact(got[ch], ref[ch], "cost channel " + nm)
+    assert np.abs(got[4:] - ref[4:]).max() <= 2e-6
+
+
 def test_unfused_pipeline_matches_fused(gpu):
     """The reference's own call sequence (get_costs -> extract_features_left) through the drop-in modules."""
     from msnets_amd import cbmv_generator as cg
