@@ -572,6 +572,19 @@ __host__ __device__ constexpr DTap dtap(int k) {
     return DTap{0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
 }
 
+// dtap(k) as one word per group for the kernel's run-time loop: dd | dh<<1 | dw<<2 | pd<<3 | ph<<4 | pw<<5 | first<<6 | last<<7
+struct DeconvTapTable { int e[27]; };
+constexpr DeconvTapTable make_deconv_taps() {
+    DeconvTapTable t{};
+    for (int k = 0; k < 27; ++k) {
+        const DTap d = dtap(k);
+        const bool first = (k == 0) || dtap(k > 0 ? k - 1 : 0).last;
+        t.e[k] = d.dd | d.dh << 1 | d.dw << 2 | d.pd << 3 | d.ph << 4 | d.pw << 5 | (first ? 64 : 0) | (d.last ? 128 : 0);
+    }
+    return t;
+}
+__constant__ DeconvTapTable kDeconvTaps = make_deconv_taps();
+
 // packed deconv weights (16-byte units): idx = ((((cg*27 + k)*KS + ks)*NB + nbl)*2 + hl)*64 + lane, k = group in dtap order,
 // element j of lane (r, h): W[ci = ks*16 + h*8 + j][co = (cg*NB + nbl)*32 + r][tap = (kd*3+kh)*3+kw]   (ConvTranspose3d layout)
 __global__ void pack_deconv_weight_f16s_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Ci, int Co,
@@ -595,6 +608,11 @@ __global__ void pack_deconv_weight_f16s_kernel(const float* __restrict__ w, _Flo
     }
 }
 
+#ifdef DEXP_NO_GBAR
+#define MSNET_DBAR() do {} while (0)
+#else
+#define MSNET_DBAR() MSNET_LDS_BARRIER()
+#endif
 template <int KS, int NB>
 __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
     constexpr int TD = 2, TH = 4, TW = 32, MB = 2;
@@ -703,10 +721,14 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
         if constexpr (NLB > 1) dst_[256] = SET.v1;                                                \
         if constexpr (NLB > 2) { dst_[512] = SET.v2; dst_[768] = SET.v3; }                        \
     } while (0)
+#if defined(DEXP_NO_B)
+#define MSNET_DGROUP(G, SET) MSNET_DBAR();
+#else
 #define MSNET_DGROUP(G, SET)                    \
     MSNET_WRITE_B(k0 + (G) + 1, SET);           \
     MSNET_ISSUE_B(k0 + (G) + 1 + 3, SET);       \
-    MSNET_LDS_BARRIER();
+    MSNET_DBAR();
+#endif
         issue_a(0);
         cg_cur = cg_of(0); cg_next = cg_of(1);
         MSNET_ISSUE_B(0, bw0);
@@ -716,11 +738,15 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
             const int k0 = it * 27;
             if (it > 0) { b_item = it; cg_cur = cg_next; cg_next = cg_of(it + 1); }
             MSNET_LDS_BARRIER();                        // b1: MFMA waves are done with the previous tile
+#ifndef DEXP_NO_A
             write_a();
+#endif
             MSNET_WRITE_B(k0, bw0);
             MSNET_ISSUE_B(k0 + 3, bw0);
             MSNET_LDS_BARRIER();                        // b2: tile and group 0 are in LDS
+#ifndef DEXP_NO_A
             if (it + 1 < nitems) issue_a(it + 1);
+#endif
             MSNET_DGROUP(0, bw1)  MSNET_DGROUP(1, bw2)  MSNET_DGROUP(2, bw0)  MSNET_DGROUP(3, bw1)  MSNET_DGROUP(4, bw2)
             MSNET_DGROUP(5, bw0)  MSNET_DGROUP(6, bw1)  MSNET_DGROUP(7, bw2)  MSNET_DGROUP(8, bw0)  MSNET_DGROUP(9, bw1)
             MSNET_DGROUP(10, bw2) MSNET_DGROUP(11, bw0) MSNET_DGROUP(12, bw1) MSNET_DGROUP(13, bw2) MSNET_DGROUP(14, bw0)
@@ -737,6 +763,7 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
     // ------------------------------ MFMA waves ------------------------------
     const int wm = wave;
     const int r = lane & 31, hh = lane >> 5;
+    [[maybe_unused]] int sidx_d = 0;
     int abase[MB];                                      // byte offset of this lane's input voxel record (+ lane-half slot)
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
@@ -744,7 +771,7 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
         const int bh = mb % TH, bd = mb / TH;
         abase[i] = ((bd * IH + bh) * IW + r) * RB + 16 * hh;
     }
-    const int stride_w = 2 * a.Co, stride_h = 2 * a.OW * a.Co;
+    const int stride_w = 2 * a.Co * 4, stride_h = 2 * a.OW * a.Co * 4;  // bytes
 
     for (int it = 0; it < nitems; ++it) {
         int n, d0, h0, w0, cg;
@@ -753,24 +780,39 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
         MSNET_LDS_BARRIER();                            // b1
         MSNET_LDS_BARRIER();                            // b2
         const int gg0 = it * 27;
-        f32x16 acc0[MB][NB], acc1[MB][NB];
+        f32x16 acc0[MB][NB], acc1[MB][NB], rres[MB][NB];
+        unsigned obase[MB][NB];                         // byte offset of the lane's first output element in sample n
         half8 ah[2][MB], al[2][MB], bh_[2][NB], bl[2][NB];
-        // the 27 groups are expanded at compile time (a 27-trip `#pragma unroll` was only partially honoured, leaving
-        // dtap() -- loops and divisions -- and the accumulator/fragment indexing to run time: 2.7 ms instead of 2.0)
-        static_for<27>([&](auto kc) {
-            constexpr int k = decltype(kc)::value;
-            constexpr DTap t = dtap(k);
-            constexpr bool first = (k == 0) || dtap(k > 0 ? k - 1 : 0).last;
-            if (first) {
+        const size_t osample = (size_t)a.OD * a.OH * a.OW * a.Co * 4;
+        const auto rs_y = make_rsrc(a.y + (size_t)n * (osample / 4), osample);
+        const auto rs_res = make_rsrc(a.res ? a.res + (size_t)n * (osample / 4) : nullptr, a.res ? osample : 0);
+        // The 27 groups run as a real loop driven by a constant table: expanded at compile time the kernel was 88 KB of
+        // straight-line code, larger than the 64 KB instruction cache two CUs share, and ran at a quarter of the speed
+        // its MFMA / LDS / HBM budgets allow.  Everything indexed by k is wave-uniform (SGPRs); the accumulators and
+        // fragment registers keep static indices.
+        for (int k = 0; k < 27; ++k) {
+            if (wave == 0) STAMP(0, sidx_d, lane);
+            const int te = __builtin_amdgcn_readfirstlane(kDeconvTaps.e[k]);
+            const int t_dd = te & 1, t_dh = (te >> 1) & 1, t_dw = (te >> 2) & 1;
+            const int t_pd = (te >> 3) & 1, t_ph = (te >> 4) & 1, t_pw = (te >> 5) & 1;
+            if (te & 64) {                              // first tap of a class: clear, and start its residual loads
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
-                    for (int j = 0; j < NB; ++j)
+                    for (int j = 0; j < NB; ++j) {
 #pragma unroll
                         for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+                        const int mb = wm * MB + i;
+                        const int ihb = h0 + mb % TH, iwb = w0 + 4 * hh, id = d0 + mb / TH;
+                        obase[i][j] = (unsigned)(((((size_t)2 * id + t_pd) * a.OH + 2 * ihb + t_ph) * a.OW + 2 * iwb + t_pw) *
+                                                     a.Co + (nb0 + j) * 32 + r) * 4u;
+                        if (id >= a.D || ihb >= a.H) obase[i][j] = 0xffffffffu;     // whole M-block outside the input
+                        residual_prefetch<32>(rres[i][j], rs_res, obase[i][j], stride_h, stride_w,
+                                              [&](int, int lw) { return obase[i][j] != 0xffffffffu && iwb + lw < a.W; });
+                    }
             }
             const unsigned char* bb = lds_b + ((gg0 + k) & 1) * GB + lane * 16;
-            const int toff = ((t.dd * IH + t.dh) * IW + t.dw) * RB;
+            const int toff = ((t_dd * IH + t_dh) * IW + t_dw) * RB;
             auto frag = [&](int ks, int slot) {
 #pragma unroll
                 for (int i = 0; i < MB; ++i) {
@@ -794,23 +836,29 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
+#ifdef DEXP_NO_MFMA
+                        acc0[i][j][0] += ah[ks & 1][i][0] * bh_[ks & 1][j][0];
+                        acc1[i][j][0] += al[ks & 1][i][0] * bl[ks & 1][j][0];
+#else
                         acc0[i][j] = mfma16(ah[ks & 1][i], bh_[ks & 1][j], acc0[i][j]);
                         acc1[i][j] = mfma16(al[ks & 1][i], bh_[ks & 1][j], acc1[i][j]);
                         acc1[i][j] = mfma16(ah[ks & 1][i], bl[ks & 1][j], acc1[i][j]);
+#endif
                     }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (k < 26) MSNET_LDS_BARRIER();            // g_k: this group's weights are consumed, the next are published
-            if (t.last) {
-                // epilogue of class (pd, ph, pw): output voxel (2*id+pd, 2*ih+ph, 2*iw+pw)
-                const bool full_hw = (h0 + TH <= a.H) && (w0 + TW <= a.W);
+            if (wave == 0) STAMP(0, sidx_d, lane);
+            if (k < 26) MSNET_DBAR();                   // g_k: this group's weights are consumed, the next are published
+            if (wave == 0) STAMP(0, sidx_d, lane);
+#ifdef DEXP_NO_EPI
+            if ((te & 128) && acc0[0][0][0] == 123.456f) {
+#else
+            if (te & 128) {
+#endif
+                // last tap of class (pd, ph, pw): epilogue to output voxels (2*id+pd, 2*ih+ph, 2*iw+pw)
 #pragma unroll
                 for (int i = 0; i < MB; ++i) {
-                    const int mb = wm * MB + i;
-                    const int bh = mb % TH, bd = mb / TH;
-                    const int id = d0 + bd;
-                    if (id >= a.D) continue;
-                    const int ihb = h0 + bh, iwb = w0 + 4 * hh;
+                    const int iwb = w0 + 4 * hh;
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
                         const int co = (nb0 + j) * 32 + r;
@@ -819,14 +867,12 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
                         f32x16 v;
 #pragma unroll
                         for (int e = 0; e < 16; ++e) v[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
-                        const size_t base = ((((size_t)n * a.OD + 2 * id + t.pd) * a.OH + 2 * ihb + t.ph) * a.OW +
-                                             2 * iwb + t.pw) * a.Co + co;
-                        epilogue_block<32>(v, sc, sh, a.res, a.y, base, stride_h, stride_w, a.relu, full_hw,
-                                           [&](int lh, int lw) { return ihb + lh < a.H && iwb + lw < a.W; });
+                        epilogue_store<32>(v, rres[i][j], sc, sh, rs_y, obase[i][j], stride_h, stride_w, a.relu,
+                                           [&](int, int lw) { return obase[i][j] != 0xffffffffu && iwb + lw < a.W; });
                     }
                 }
             }
-        });
+        }
     }
 }
 

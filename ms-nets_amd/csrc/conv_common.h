@@ -117,6 +117,42 @@ __device__ __forceinline__ void epilogue_block(const f32x16& acc, float sc, floa
     }
 }
 
+// The same epilogue in two halves over buffer descriptors, for kernels that can issue the residual loads long before the
+// accumulators are final (the loads' HBM latency then hides behind the MFMA groups instead of stalling each batch: with
+// one resident block per CU the batched form above keeps only ~16 KB in flight per CU, a quarter of what HBM needs).
+// Both halves are branch-free: an element outside the tensor gets byte offset 0xffffffff, which the buffer bounds check
+// turns into "load 0" / "store dropped".  (With per-element `if`s the compiler's waitcnt pass put s_waitcnt vmcnt(0) in
+// front of every store, i.e. each store waited for the previous store's acknowledgement: 9000 cycles per 32 stores.)
+// `off` = byte offset of the lane's (row 0, col 0) element inside the buffer; strides in bytes.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0xfffffffcu ? 0xfffffffcu : bytes), 0x00020000);
+}
+
+template <int BW, class Valid>
+__device__ __forceinline__ void residual_prefetch(f32x16& rv, __amdgpu_buffer_rsrc_t res, unsigned off, int stride_h,
+                                                  int stride_w, Valid valid) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = (e & 3) + 8 * (e >> 2);
+        const unsigned o = valid(c / BW, c % BW) ? off + (unsigned)((c / BW) * stride_h + (c % BW) * stride_w) : 0xffffffffu;
+        rv[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(res, o, 0, 0));
+    }
+}
+
+template <int BW, class Valid>
+__device__ __forceinline__ void epilogue_store(const f32x16& acc, const f32x16& rv, float sc, float sh,
+                                               __amdgpu_buffer_rsrc_t y, unsigned off, int stride_h, int stride_w, int relu,
+                                               Valid valid) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int c = (e & 3) + 8 * (e >> 2);
+        const unsigned o = valid(c / BW, c % BW) ? off + (unsigned)((c / BW) * stride_h + (c % BW) * stride_w) : 0xffffffffu;
+        float v = acc[e] * sc + sh + rv[e];
+        if (relu) v = fmaxf(v, 0.f);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y, o, 0, 0);
+    }
+}
+
 // LDS-only workgroup barrier: orders LDS traffic across the s_barrier without draining the vector-memory
 // counter (a plain __syncthreads() may add s_waitcnt vmcnt(0), which would stall the compute waves on their
 // in-flight weight loads and the loader waves on nothing useful).

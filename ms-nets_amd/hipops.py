@@ -48,9 +48,9 @@ def pack_conv_weight(w, transposed=False, f16s=False, stride=1):
 
 PRECISIONS = ("fp32", "split-fp16")
 _default_precision = "split-fp16"
-# The split-fp16 transposed-conv kernel is correct (tests/test_gpu_aggregators.py) but, at 27 weight-group barriers and 8
-# strided epilogues per tile, currently slower than the fp32-MFMA one (2.8 vs 2.0 ms on deconvbn4): opt-in only.
-USE_F16S_DECONV = False
+# Transposed convs with a split-fp16 kernel (Ci = 64) use it: 1.22 vs 1.99 ms on deconvbn4, 0.28 vs 0.84 ms on deconvbn3
+# (profiles/r01l_*); the rest (deconvbn1, 128 -> 64 on a 6x17x30 grid) stay on the fp32 MFMA.
+USE_F16S_DECONV = True
 
 
 def set_default_precision(p):
