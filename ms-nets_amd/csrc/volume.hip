@@ -526,7 +526,7 @@ __device__ __forceinline__ void zsad_costs(const FusedArgs& a, int yb, int xb, F
 // The raw costs are parked in the cost channel's own output slots (written and re-read by the same thread, so they
 // stay in L2 and need no fence), then overwritten with the normalised cost in the last pass.
 template <int M, int WS>
-__global__ __launch_bounds__(256) void features_fused_kernel(FusedArgs a) {
+__device__ __forceinline__ void features_fused(const FusedArgs& a) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= a.Wc || y >= a.Hc) return;
     const int yb = y + a.bh, xb = x + a.bw;
@@ -554,10 +554,16 @@ __global__ __launch_bounds__(256) void features_fused_kernel(FusedArgs a) {
     }
 }
 
-template <int M, int WS>
-static void launch_features(const char* name, const FusedArgs& a, hipStream_t s) {
-    LaunchScope ls(name, s, 0, 4.0 * 2.0 * a.nd * (double)a.Hc * a.Wc);
-    hipLaunchKernelGGL((features_fused_kernel<M, WS>), dim3(cdiv(a.Wc, 64), cdiv(a.Hc, 4)), dim3(256), 0, s, a);
+// All four matchers in one launch (blockIdx.z picks the matcher, most expensive first): a matcher alone has only
+// Hc*Wc = 130 K threads, two waves per SIMD, and is bound by the latency of its dependent loads; together they overlap.
+template <int CW, int NW, int SW, int ZW>
+__global__ __launch_bounds__(256) void features_all_kernel(FusedArgs a) {
+    switch (blockIdx.z) {
+    case 0: features_fused<3, ZW>(a); break;
+    case 1: features_fused<1, NW>(a); break;
+    case 2: features_fused<2, SW>(a); break;
+    default: features_fused<0, CW>(a); break;
+    }
 }
 
 static inline int grid1d(size_t total, int cap = 16384) {
@@ -769,9 +775,13 @@ extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, in
         LaunchScope ls("sadsob_horizontal", s, 0, 8.0 * ndisp * (double)(Hb + 1) * (Wb + 1));
         hipLaunchKernelGGL(sadsob_horizontal_kernel, dim3(cdiv(Hb + 1, 64), ndisp), dim3(64), 0, s, integ, Hb, Wb, ndisp);
     }
-    if (p.censw == 11) launch_features<0, 11>("features_census", a, s); else launch_features<0, 0>("features_census", a, s);
-    if (p.nccw == 3)   launch_features<1, 3>("features_ncc", a, s);     else launch_features<1, 0>("features_ncc", a, s);
-    if (p.sobelw == 5) launch_features<2, 5>("features_sobel", a, s);   else launch_features<2, 0>("features_sobel", a, s);
-    if (p.sadw == 5)   launch_features<3, 5>("features_zsad", a, s);    else launch_features<3, 0>("features_zsad", a, s);
+    {
+        LaunchScope ls("features", s, 0, 4.0 * 8.0 * ndisp * (double)Hc * Wc);
+        const dim3 gf(cdiv(Wc, 64), cdiv(Hc, 4), 4);
+        if (p.censw == 11 && p.nccw == 3 && p.sobelw == 5 && p.sadw == 5)
+            hipLaunchKernelGGL((features_all_kernel<11, 3, 5, 5>), gf, dim3(256), 0, s, a);
+        else
+            hipLaunchKernelGGL((features_all_kernel<0, 0, 0, 0>), gf, dim3(256), 0, s, a);
+    }
     return check_launch("msnet_build_volume");
 }

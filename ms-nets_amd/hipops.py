@@ -166,7 +166,6 @@ class ConvBNPlan:
             self.f16s = bool(USE_F16S_DECONV and lib.msnet_deconv3d_k3s2_f16s_supported(ci, self.co))
         else:
             self.f16s = bool(lib.msnet_conv3d_k3_f16s_supported(ci, self.co, stride))
-        self.wpk = pack_conv_weight(w, transposed, f16s=self.f16s, stride=stride)
         if bn is not None:
             inv = 1.0 / torch.sqrt(bn.running_var.detach().float() + bn.eps)
             self.scale = (bn.weight.detach().float() * inv).contiguous()
@@ -174,6 +173,13 @@ class ConvBNPlan:
         else:
             self.scale = None
             self.shift = None if conv.bias is None else conv.bias.detach().float().contiguous()
+        if self.f16s and self.scale is not None:
+            # split-fp16 kernels: the BN scale goes into the packed weights (one fp32 multiply per weight before the
+            # hi/lo split) and the shift becomes the accumulators' start value, so their epilogue has no constants.
+            shape = (1, -1, 1, 1, 1) if transposed else (-1, 1, 1, 1, 1)
+            w = w.float() * self.scale.view(shape)
+            self.scale = None
+        self.wpk = pack_conv_weight(w, transposed, f16s=self.f16s, stride=stride)
 
 
 def state_key(module):
