@@ -9,6 +9,13 @@
 //   msnet_deconv3d_cout1      : gcnet_3dcnn.py:88-92 un-fused (stride 2, or stride 4 / output_padding 3)
 #include "common.h"
 
+#ifndef TAIL_RT
+#define TAIL_RT 8
+#endif
+#ifndef TAIL_CPT
+#define TAIL_CPT 1
+#endif
+
 namespace msnet {
 
 // Online softmax state for sum_d d * softmax(x)_d.
@@ -69,11 +76,14 @@ struct SliceStage {
 // so each staged slice yields three partial sums per output pixel (kd = 0,1,2); the kd=2 partial is
 // carried to the next slice.  27*CI MACs per input voxel, exactly the dense definition.
 // ---------------------------------------------------------------------------------------------
-template <int CI, bool WRITE_LOGITS, int TH>
-__global__ __launch_bounds__(TH * 32) void deconv5_tail_kernel(const float* __restrict__ x, const float* __restrict__ w,
+// Thread = CPT vertically adjacent input columns: every weight read from the LDS table (a broadcast ds_read_b128 costs
+// the LDS a full 4-cycle slot for 16 useful bytes) then feeds CPT*27 FMAs instead of 27; with one column per thread the
+// kernel was bound by those reads (896 LDS cycles per wave-slice against 864 FMA issue slots), not by the VALU.
+template <int CI, bool WRITE_LOGITS, int RT, int CPT>
+__global__ __launch_bounds__(RT * 32) void deconv5_tail_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                float bias, float* __restrict__ out, int N, int D, int H,
                                                                int W, int nth, int ntw) {
-    constexpr int TW = 32, IH = TH + 1, IW = TW + 1, PS = CI + 4, NT = TH * 32;
+    constexpr int TH = RT * CPT, TW = 32, IH = TH + 1, IW = TW + 1, PS = CI + 4, NT = RT * 32;
     __shared__ __attribute__((aligned(16))) float lds[IH * IW * PS];
     // The 27*CI weights are wave-uniform.  As SGPR operands they cost ~55 exposed scalar-cache round trips per slice
     // (SMEM returns out of order => lgkmcnt(0) each batch): 20K cycles per wave-slice for 880 FMAs (r01g: 1.84 ms).
@@ -85,23 +95,26 @@ __global__ __launch_bounds__(TH * 32) void deconv5_tail_kernel(const float* __re
     const int tw = bid % ntw; bid /= ntw;
     const int th = bid % nth;
     const int n = bid / nth;
-    const int tid = threadIdx.x, lh = tid >> 5, lw = tid & 31;
+    const int tid = threadIdx.x, lh = (tid >> 5) * CPT, lw = tid & 31;
     const int h0 = th * TH, w0 = tw * TW, h = h0 + lh, wq = w0 + lw;
     const int OH = 2 * H, OW = 2 * W, OD = 2 * D;
 
-    SoftArg sa[4];
+    SoftArg sa[CPT][4];
+    float carry[CPT][4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) sa[c].init();
-    float carry[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool live = (h < H) && (wq < W);
+    for (int j = 0; j < CPT; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sa[j][c].init(); carry[j][c] = 0.f; }
 
     stg.load(x, (size_t)n * D * H * W, H, W, h0, w0, tid, true);
     for (int P = 0; P <= D; ++P) {
-        float p[3][4];
+        float p[CPT][3][4];
 #pragma unroll
-        for (int kd = 0; kd < 3; ++kd)
+        for (int j = 0; j < CPT; ++j)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) p[kd][c] = 0.f;
+            for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) p[j][kd][c] = 0.f;
         if (P < D) {
             __syncthreads();                            // everyone is done reading slice P-1
             stg.store(lds, tid);
@@ -109,9 +122,9 @@ __global__ __launch_bounds__(TH * 32) void deconv5_tail_kernel(const float* __re
             stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0, w0, tid, P + 1 < D);   // in flight during the FMAs
 #pragma unroll 1
             for (int c4 = 0; c4 < CI / 4; ++c4) {     // rolled: a full unroll keeps hundreds of weights live (1 wave/SIMD)
-                f32x4 xv[2][2];
+                f32x4 xv[CPT + 1][2];
 #pragma unroll
-                for (int dh = 0; dh < 2; ++dh)
+                for (int dh = 0; dh <= CPT; ++dh)
 #pragma unroll
                     for (int dw = 0; dw < 2; ++dw)
                         xv[dh][dw] = *reinterpret_cast<const f32x4*>(lds + ((lh + dh) * IW + lw + dw) * PS + c4 * 4);
@@ -124,48 +137,167 @@ __global__ __launch_bounds__(TH * 32) void deconv5_tail_kernel(const float* __re
                         wc[k4 * 4] = t4[0]; wc[k4 * 4 + 1] = t4[1]; wc[k4 * 4 + 2] = t4[2]; wc[k4 * 4 + 3] = t4[3];
                     }
 #pragma unroll
-                    for (int kd = 0; kd < 3; ++kd)
+                    for (int j = 0; j < CPT; ++j)
 #pragma unroll
-                        for (int ph = 0; ph < 2; ++ph)
+                        for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
-                            for (int pw = 0; pw < 2; ++pw)
+                            for (int ph = 0; ph < 2; ++ph)
 #pragma unroll
-                                for (int dh = 0; dh <= ph; ++dh)
+                                for (int pw = 0; pw < 2; ++pw)
 #pragma unroll
-                                    for (int dw = 0; dw <= pw; ++dw) {
-                                        const int kh = ph ? (dh ? 0 : 2) : 1;
-                                        const int kw = pw ? (dw ? 0 : 2) : 1;
-                                        p[kd][ph * 2 + pw] += xv[dh][dw][cc] * wc[kd * 9 + kh * 3 + kw];
-                                    }
+                                    for (int dh = 0; dh <= ph; ++dh)
+#pragma unroll
+                                        for (int dw = 0; dw <= pw; ++dw) {
+                                            const int kh = ph ? (dh ? 0 : 2) : 1;
+                                            const int kw = pw ? (dw ? 0 : 2) : 1;
+                                            p[j][kd][ph * 2 + pw] += xv[j + dh][dw][cc] * wc[kd * 9 + kh * 3 + kw];
+                                        }
                 }
             }
         }
         // output slices finished by this input slice
-        if (WRITE_LOGITS) {
-            if (live) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j) {
+            const bool live = (h + j < H) && (wq < W);
+            if (WRITE_LOGITS) {
+                if (live) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const size_t pix = (size_t)(2 * (h + j) + (c >> 1)) * OW + (2 * wq + (c & 1));
+                        if (P >= 1) out[((size_t)n * OD + (2 * P - 1)) * OH * OW + pix] = carry[j][c] + p[j][0][c] + bias;
+                        if (P < D)  out[((size_t)n * OD + 2 * P) * OH * OW + pix] = p[j][1][c] + bias;
+                    }
+                }
+            } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const size_t pix = (size_t)(2 * h + (c >> 1)) * OW + (2 * wq + (c & 1));
-                    if (P >= 1) out[((size_t)n * OD + (2 * P - 1)) * OH * OW + pix] = carry[c] + p[0][c] + bias;
-                    if (P < D)  out[((size_t)n * OD + 2 * P) * OH * OW + pix] = p[1][c] + bias;
+                    const float lo = carry[j][c] + p[j][0][c] + bias, hi = p[j][1][c] + bias;
+                    if (P >= 1 && P < D) sa[j][c].push2(lo, (float)(2 * P - 1), hi, (float)(2 * P));
+                    else if (P < D)      sa[j][c].push(hi, (float)(2 * P));
+                    else                 sa[j][c].push(lo, (float)(2 * P - 1));
                 }
             }
-        } else {
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float lo = carry[c] + p[0][c] + bias, hi = p[1][c] + bias;
-                if (P >= 1 && P < D) sa[c].push2(lo, (float)(2 * P - 1), hi, (float)(2 * P));
-                else if (P < D)      sa[c].push(hi, (float)(2 * P));
-                else                 sa[c].push(lo, (float)(2 * P - 1));
+            for (int c = 0; c < 4; ++c) carry[j][c] = p[j][2][c];
+        }
+    }
+    if (!WRITE_LOGITS) {
+#pragma unroll
+        for (int j = 0; j < CPT; ++j)
+            if ((h + j < H) && (wq < W)) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    out[((size_t)n * OH + (2 * (h + j) + (c >> 1))) * OW + (2 * wq + (c & 1))] = sa[j][c].result();
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// deconv5 + softmax + disparity regression with the channel contraction on the fp32 MFMA.
+// Per input slice the work is a [27 taps (padded to 32)] x [32 channels] x [voxels] product with NO halo: every input voxel's 27
+// tap partials T[voxel][tap] are computed once (v_mfma_f32_32x32x2_f32: fp32 operands, exact products), parked in LDS,
+// and each output pixel then adds the 1..8 partials of its 2x2 input neighbourhood (27 LDS reads + adds per input column
+// and slice instead of 864 FMAs and 256 broadcast weight reads).  The weights are operand A and live in 16 VGPRs for the
+// whole kernel: lane (tap = l & 31, kq = l >> 5), K-step s <-> channel s + 16*kq; operand B is the lane's voxel
+// (l & 31 of the M-block row) with the same channel.  The result has lane = voxel, register e = tap (e&3) + 8*(e>>2) + 4*kq.
+// A workgroup owns 8 x 32 input voxels per slice (8 M-blocks, two per wave) and finishes the 7 x 31 columns whose
+// neighbours (h+1, w+1) are inside it; tiles overlap by one row / column (18 % extra MFMA work, no halo exchange).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void deconv5_tail_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                float bias, float* __restrict__ out, int N, int D, int H,
+                                                                int W, int nth, int ntw) {
+    constexpr int CI = 32, TH = 8, TW = 32, UH = 7, UW = 31, PS = CI + 4, TS = 33, NT = 256;
+    __shared__ __attribute__((aligned(16))) float xs[TH * TW * PS];
+    __shared__ float ts[TH * TW * TS];
+    SliceStage<CI, TH, TW, NT> stg;
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw = bid % ntw; bid /= ntw;
+    const int th = bid % nth;
+    const int n = bid / nth;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, kq = lane >> 5;
+    const int h0 = th * UH, w0 = tw * UW;
+    const int r = tid >> 5, c = tid & 31;               // gather role: input column (h0 + r, w0 + c)
+    const int h = h0 + r, wq = w0 + c;
+    const bool live = r < UH && c < UW && h < H && wq < W;
+    const int OH = 2 * H, OW = 2 * W;
+
+    float aw[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) aw[s] = (j < 27) ? w[(s + 16 * kq) * 27 + j] : 0.f;
+
+    SoftArg sa[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sa[q].init();
+    float carry[4] = {0.f, 0.f, 0.f, 0.f};
+
+    stg.load(x, (size_t)n * D * H * W, H, W, h0, w0, tid, true);
+    for (int P = 0; P <= D; ++P) {
+        float p[3][4];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p[kd][q] = 0.f;
+        if (P < D) {
+            __syncthreads();                            // slice P-1: gathers done, xs free
+            stg.store(xs, tid);
+            __syncthreads();
+            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0, w0, tid, P + 1 < D);   // in flight during the MFMAs
+            f32x4 b[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* src = xs + ((wave * 2 + i) * 32 + j) * PS + 16 * kq;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) b[i][q] = *reinterpret_cast<const f32x4*>(src + 4 * q);
+            }
+            f32x16 acc[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s], b[i][s >> 2][s & 3], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float* dst = ts + ((wave * 2 + i) * 32 + j) * TS + 4 * kq;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[(e & 3) + 8 * (e >> 2)] = acc[i][e];
+            }
+            __syncthreads();
+            if (live) {
+                const float* t0 = ts + (r * 32 + c) * TS;
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+                        for (int pw = 0; pw < 2; ++pw)
+#pragma unroll
+                            for (int dh = 0; dh <= ph; ++dh)
+#pragma unroll
+                                for (int dw = 0; dw <= pw; ++dw) {
+                                    const int kh = ph ? (dh ? 0 : 2) : 1;
+                                    const int kw = pw ? (dw ? 0 : 2) : 1;
+                                    p[kd][ph * 2 + pw] += t0[(dh * 32 + dw) * TS + kd * 9 + kh * 3 + kw];
+                                }
             }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) carry[c] = p[2][c];
+        for (int q = 0; q < 4; ++q) {
+            const float lo = carry[q] + p[0][q] + bias, hi = p[1][q] + bias;
+            if (P >= 1 && P < D) sa[q].push2(lo, (float)(2 * P - 1), hi, (float)(2 * P));
+            else if (P < D)      sa[q].push(hi, (float)(2 * P));
+            else                 sa[q].push(lo, (float)(2 * P - 1));
+            carry[q] = p[2][q];
+        }
     }
-    if (!WRITE_LOGITS && live) {
+    if (live) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-            out[((size_t)n * OH + (2 * h + (c >> 1))) * OW + (2 * wq + (c & 1))] = sa[c].result();
+        for (int q = 0; q < 4; ++q)
+            out[((size_t)n * OH + (2 * h + (q >> 1))) * OW + (2 * wq + (q & 1))] = sa[q].result();
     }
 }
 
@@ -343,13 +475,22 @@ extern "C" int msnet_deconv5_softargmin(const float* x, const float* w, float bi
     if (!x || !w || !disp) return fail("msnet_deconv5_softargmin: null pointer");
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_deconv5_softargmin: empty input");
     if (Ci != 32) return fail("msnet_deconv5_softargmin: Ci=%d (only 32 is built)", Ci);
-    constexpr int TH = 4;       // 4x32 input columns / 128 threads per workgroup: 1020 workgroups at 272x480, 6 per CU
+#ifdef TAIL_VALU
+    constexpr int RT = TAIL_RT, CPT = TAIL_CPT, TH = RT * CPT;
     const int nth = cdiv(H, TH), ntw = cdiv(W, 32);
+#else
+    const int nth = cdiv(H, 7), ntw = cdiv(W, 31);
+#endif
     hipStream_t s = (hipStream_t)stream;
     const double vox = (double)N * D * H * W;
     LaunchScope ls("deconv5_softargmin", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + 4.0 * N * H * W));
-    hipLaunchKernelGGL((deconv5_tail_kernel<32, false, TH>), dim3((unsigned)(N * nth * ntw)), dim3(TH * 32), 0, s, x, w,
+#ifdef TAIL_VALU
+    hipLaunchKernelGGL((deconv5_tail_kernel<32, false, RT, CPT>), dim3((unsigned)(N * nth * ntw)), dim3(RT * 32), 0, s, x, w,
                        bias, disp, N, D, H, W, nth, ntw);
+#else
+    hipLaunchKernelGGL(deconv5_tail_mfma_kernel, dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, bias, disp, N, D, H, W,
+                       nth, ntw);
+#endif
     return check_launch("msnet_deconv5_softargmin");
 }
 
@@ -363,7 +504,7 @@ extern "C" int msnet_deconv3d_cout1(const float* x, const float* w, float bias, 
     if (stride == 2 && Ci == 32) {
         const int nth = cdiv(H, 8), ntw = cdiv(W, 32);
         LaunchScope ls("deconv5_logits", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + 8.0 * vox));
-        hipLaunchKernelGGL((deconv5_tail_kernel<32, true, 8>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w,
+        hipLaunchKernelGGL((deconv5_tail_kernel<32, true, 8, 1>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w,
                            bias, logits, N, D, H, W, nth, ntw);
         return check_launch("msnet_deconv3d_cout1");
     }
