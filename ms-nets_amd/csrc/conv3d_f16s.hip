@@ -876,6 +876,176 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// First layer (8 input channels, stride 1) on the split-fp16 MFMA.  With 8 channels a 16-wide K-step holds TWO taps: lane
+// half hh of the A operand reads the voxel shifted by tap 2s+hh (8 channels = one 16-byte fragment), so the 27 taps
+// take 14 K-steps instead of 27 half-empty ones.  LDS records are 32 bytes (hi | lo of the 8 channels, the two halves
+// swapped on odd 8-voxel groups so 16 consecutive voxels cover all 64 banks), a 2x4x32 tile plus ALL weights is 54 KB:
+// two workgroups per CU, no wave specialisation -- every wave loads, splits, multiplies and stores, and the other
+// workgroup's MFMAs cover this one's staging and its 32 KB of output stores (this layer is HBM-store heavy).
+//   packed weights (16-byte units): idx = ((s*NB + nb)*2 + hl)*64 + lane, element j of lane (r, hh):
+//       W[co = nb*32 + r][ci = j][tap = 2s + hh]  (zero for tap 27);  hl = 0 hi, 1 lo.
+// ---------------------------------------------------------------------------------------------
+__global__ void pack_weight_c8_f16s_kernel(const float* __restrict__ w, _Float16* __restrict__ out, int Co) {
+    const int NB = Co / 32;
+    const size_t total = (size_t)14 * NB * 2 * 64 * 8;
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        size_t i = o;
+        const int j = i & 7; i >>= 3;
+        const int lane = i & 63; i >>= 6;
+        const int hl = i & 1; i >>= 1;
+        const int nb = i % NB;
+        const int sstep = (int)(i / NB);
+        const int tap = 2 * sstep + (lane >> 5), co = nb * 32 + (lane & 31);
+        const float v = tap < 27 ? w[((size_t)co * 8 + j) * 27 + tap] : 0.f;
+        const _Float16 h = (_Float16)v;
+        out[o] = hl ? (_Float16)((v - (float)h) * kLoScale) : h;
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(256, 2) void conv3d_c8_f16s_kernel(ConvArgs a) {
+    constexpr int TD = 2, TH = 4, TW = 32, ID = TD + 2, IH = TH + 2, IW = TW + 2, NPOS = ID * IH * IW;
+    constexpr int NSLOT = NPOS * 2, NL = (NSLOT + 255) / 256;           // float4 (channel quads) per thread per tile
+    constexpr int WB = 14 * NB * 2 * 1024;
+    __shared__ __attribute__((aligned(16))) unsigned char lds_a[NPOS * 32];
+    __shared__ __attribute__((aligned(16))) unsigned char lds_b[WB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const unsigned G = gridDim.x, lb = xcd_remap(blockIdx.x, G);
+    const unsigned T = (unsigned)a.N * a.ntd * a.nth * a.ntw;
+    const int nitems = (T > lb) ? (int)((T - lb + G - 1) / G) : 0;
+    if (nitems == 0) return;
+    {
+        const u32x4* src = reinterpret_cast<const u32x4*>(a.wpk);
+        u32x4* dst = reinterpret_cast<u32x4*>(lds_b);
+        for (int k = tid; k < WB / 16; k += 256) dst[k] = src[k];
+    }
+    auto decode = [&](int it, int& n, int& d0, int& h0, int& w0) {
+        unsigned t = lb + (unsigned)it * G;
+        w0 = (t % a.ntw) * TW; t /= a.ntw;
+        h0 = (t % a.nth) * TH; t /= a.nth;
+        d0 = (t % a.ntd) * TD;
+        n = t / a.ntd;
+    };
+    // loader role: slot = u*256 + tid -> (pos = slot >> 1, quad = slot & 1)
+    const size_t isample = (size_t)a.D * a.H * a.W * 8 * 4;
+    f32x4 av[NL];
+    auto issue_a = [&](int it) {
+        int n, d0, h0, w0;
+        decode(it, n, d0, h0, w0);
+        const auto rsrc = make_rsrc(a.x + (size_t)n * (isample / 4), isample);
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int slot = u * 256 + tid, pos = slot >> 1, q = slot & 1;
+            const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
+            const int gd = d0 - 1 + id, gh = h0 - 1 + ih, gw = w0 - 1 + iw;
+            const bool ok = slot < NSLOT && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+            const unsigned voff = ok ? (unsigned)((((size_t)gd * a.H + gh) * a.W + gw) * 8 + q * 4) * 4u : 0xffffffffu;
+            av[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+        }
+    };
+    auto write_a = [&]() {
+#pragma unroll
+        for (int u = 0; u < NL; ++u) {
+            const int slot = u * 256 + tid, pos = slot >> 1, q = slot & 1;
+            if (slot < NSLOT) {
+                half4 hi, lo;
+                split4(av[u], hi, lo);
+                const int sw = ((pos >> 3) & 1) * 16;
+                *reinterpret_cast<half4*>(lds_a + pos * 32 + sw + q * 8) = hi;
+                *reinterpret_cast<half4*>(lds_a + pos * 32 + (sw ^ 16) + q * 8) = lo;
+            }
+        }
+    };
+    // MFMA role: wave owns M-blocks (bd = wave >> 1, bh = (wave & 1)*2 + i), i = 0..1
+    int vox0[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vox0[i] = ((wave >> 1) * IH + (wave & 1) * 2 + i) * IW + r;
+    const size_t osample = (size_t)a.OD * a.OH * a.OW * a.Co * 4;
+
+    issue_a(0);
+    for (int it = 0; it < nitems; ++it) {
+        int n, d0, h0, w0;
+        decode(it, n, d0, h0, w0);
+        __syncthreads();                                // previous tile fully consumed (and the weights are in LDS)
+        write_a();
+        __syncthreads();
+        if (it + 1 < nitems) issue_a(it + 1);           // in flight during the MFMAs and the epilogue
+        f32x16 acc0[2][NB], acc1[2][NB];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+        static_for<14>([&](auto sc_) {
+            constexpr int sstep = decltype(sc_)::value;
+            constexpr int t0 = 2 * sstep, t1 = 2 * sstep + 1 < 27 ? 2 * sstep + 1 : 26;
+            constexpr int off0 = ((t0 / 9) * IH + (t0 / 3) % 3) * IW + t0 % 3;
+            constexpr int off1 = ((t1 / 9) * IH + (t1 / 3) % 3) * IW + t1 % 3;
+            half8 ah[2], al[2], bh_[NB], bl[NB];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int pos = vox0[i] + (hh ? off1 : off0);
+                const int sw = ((pos >> 3) & 1) * 16;
+                ah[i] = *reinterpret_cast<const half8*>(lds_a + pos * 32 + sw);
+                al[i] = *reinterpret_cast<const half8*>(lds_a + pos * 32 + (sw ^ 16));
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                bh_[j] = *reinterpret_cast<const half8*>(lds_b + ((sstep * NB + j) * 2) * 1024 + lane * 16);
+                bl[j] = *reinterpret_cast<const half8*>(lds_b + ((sstep * NB + j) * 2 + 1) * 1024 + lane * 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    acc0[i][j] = mfma16(ah[i], bh_[j], acc0[i][j]);
+                    acc1[i][j] = mfma16(al[i], bh_[j], acc1[i][j]);
+                    acc1[i][j] = mfma16(ah[i], bl[j], acc1[i][j]);
+                }
+        });
+        // epilogue: lane = output channel, register e = voxel (e&3) + 8*(e>>2) + 4*hh of the 32-voxel row
+        const auto rs_y = make_rsrc(a.y + (size_t)n * (osample / 4), osample);
+        const auto rs_res = make_rsrc(a.res ? a.res + (size_t)n * (osample / 4) : nullptr, a.res ? osample : 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int od = d0 + (wave >> 1), oh = h0 + (wave & 1) * 2 + i, owb = w0 + 4 * hh;
+            const bool rowok = od < a.OD && oh < a.OH;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int co = j * 32 + r;
+                const float sc = a.scale ? a.scale[co] : 1.f;
+                const float sh = a.shift ? a.shift[co] : 0.f;
+                const unsigned off = (unsigned)((((size_t)od * a.OH + oh) * a.OW + owb) * a.Co + co) * 4u;
+                auto valid = [&](int, int lw) { return rowok && owb + lw < a.OW; };
+                f32x16 v, rv;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) v[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
+                residual_prefetch<32>(rv, rs_res, off, 0, a.Co * 4, valid);
+                epilogue_store<32>(v, rv, sc, sh, rs_y, off, 0, a.Co * 4, a.relu, valid);
+            }
+        }
+    }
+}
+
+template <int NB>
+static int launch_c8_f16s(const char* name, ConvArgs a, hipStream_t s) {
+    a.ntd = cdiv(a.OD, 2); a.nth = cdiv(a.OH, 4); a.ntw = cdiv(a.OW, 32);
+    const size_t ntiles = (size_t)a.N * a.ntd * a.nth * a.ntw;
+    if (ntiles == 0 || ntiles > 0x7fffffffu) return fail("%s: bad tile count %zu", name, ntiles);
+    if ((size_t)a.OD * a.OH * a.OW * a.Co * 4 > 0xfffffff0u || (size_t)a.D * a.H * a.W * 32 > 0xfffffff0u)
+        return fail("%s: a sample exceeds the 4 GB buffer-descriptor range", name);
+    const size_t cap = 2 * (size_t)num_cus();
+    const size_t nblk = ntiles < cap ? ntiles : cap;
+    const double vox = (double)a.N * a.OD * a.OH * a.OW;
+    LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
+                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
+    hipLaunchKernelGGL((conv3d_c8_f16s_kernel<NB>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+    return check_launch(name);
+}
+
 template <int KS, int NB>
 static int launch_deconv_f16s(const char* name, ConvArgs a, hipStream_t s) {
     a.ntd = cdiv(a.D, 2); a.nth = cdiv(a.H, 4); a.ntw = cdiv(a.W, 32);
@@ -924,6 +1094,12 @@ extern "C" int msnet_pack_conv_weight_f16s(const float* w, void* packed, int Ci,
         return fail("msnet_pack_conv_weight_f16s: unsupported Ci=%d Co=%d stride=%d", Ci, Co, stride);
     const int KS = (Ci == 8 || stride == 2) ? 1 : 2;    // 16-channel K-steps per staged chunk
     if (Co <= 0 || Co % 32 != 0) return fail("msnet_pack_conv_weight_f16s: Co=%d must be a positive multiple of 32", Co);
+    if (Ci == 8) {                                      // first-layer kernel: two taps per K-step
+        hipStream_t s8 = (hipStream_t)stream;
+        LaunchScope ls("pack_weight_f16s", s8, 0, 6.0 * 28 * 8 * Co);
+        hipLaunchKernelGGL(pack_weight_c8_f16s_kernel, dim3(64), dim3(256), 0, s8, w, (_Float16*)packed, Co);
+        return check_launch("msnet_pack_conv_weight_f16s");
+    }
     const size_t total = (size_t)27 * (Ci < 16 ? 16 : Ci) * Co * 2;
     const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipStream_t s = (hipStream_t)stream;
@@ -954,8 +1130,8 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
         return launch_f16s<2, 2, 32, 32, 1, 2, false, 1, false, 2>("conv3d_s2_f16s", a, s);
     //                                    TD TH TW  BW MB NB
     if (Ci == 8) {
-        if (Co == 64) return launch_f16s<2, 4, 32, 32, 2, 2, false, 1, false>("conv3d_s1_c8_f16s", a, s);
-        return launch_f16s<2, 6, 32, 32, 3, 1, false, 1, true>("conv3d_s1_c8_f16s", a, s);
+        if (Co == 64) return launch_c8_f16s<2>("conv3d_s1_c8_f16s", a, s);
+        return launch_c8_f16s<1>("conv3d_s1_c8_f16s", a, s);
     }
     if (Co % 64 == 0) return launch_f16s<2, 4, 32, 32, 2, 2, true, 2, false>("conv3d_s1_f16s_co64", a, s);
     return launch_f16s<2, 4, 32, 32, 2, 1, false, 2, false>("conv3d_s1_f16s_co32", a, s);
