@@ -120,7 +120,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     constexpr int HB = 2 * CC;                          // bytes of the hi (or lo) half of a voxel record
     constexpr int RB = SWZ ? 2 * HB : 2 * HB + 16;      // bytes per voxel record in LDS (hi + lo [+ 16 pad])
     static_assert(!SWZ || KS == 2, "the swizzle is written for 128-byte records");
-    static_assert(BW == 32, "bank-conflict analysis assumes M-blocks of 32 consecutive voxels");
+    // M-blocks of 32 consecutive voxels read conflict-free; BW = 16 (two 16-voxel rows) leaves one of the four
+    // ds_read_b128 lane groups 2-way conflicted on 4 lanes with the 128-byte swizzle -- accepted for the 16-mod-32 widths.
+    static_assert(BW == 32 || (BW == 16 && SWZ), "M-block shapes the LDS layouts were checked for");
     constexpr int MW = TW / BW, MH = TH / BH;
     constexpr int V = CC / 4;                           // float4 per voxel record half-row (incl. zero padding)
     constexpr int NPOS = ID * IH * IW;
@@ -249,7 +251,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
                 if (u < u0 || u >= u1) continue;
                 if (u * 256 + lt < PSLOT) {
                     half4 hi, lo;
+#ifdef EXP_NO_SPLIT
+                    {   // diagnostic: pure copy (wrong numerics) -- what the loader costs without the split VALU work
+                        struct H2 { half4 a, b; };
+                        const H2 t = __builtin_bit_cast(H2, av[pl][u]);
+                        hi = t.a; lo = t.b;
+                    }
+#else
                     split4(av[pl][u], hi, lo);
+#endif
                     const int off = lhi_[pl] + u * (256 / VR) * RB;
                     *reinterpret_cast<half4*>(lds + off) = hi;
                     *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ 64) : off + HB)) = lo;
@@ -1133,7 +1143,11 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
         if (Co == 64) return launch_c8_f16s<2>("conv3d_s1_c8_f16s", a, s);
         return launch_c8_f16s<1>("conv3d_s1_c8_f16s", a, s);
     }
-    if (Co % 64 == 0) return launch_f16s<2, 4, 32, 32, 2, 2, true, 2, false>("conv3d_s1_f16s_co64", a, s);
+    if (Co % 64 == 0) {
+        // widths that are 16 mod 32 (240, 120, ...): 16-wide M-block rows leave no half-empty edge tile and a smaller halo
+        if (W % 32 == 16 && H % 8 == 0) return launch_f16s<2, 8, 16, 16, 2, 2, true, 2, false>("conv3d_s1_f16s_co64", a, s);
+        return launch_f16s<2, 4, 32, 32, 2, 2, true, 2, false>("conv3d_s1_f16s_co64", a, s);
+    }
     return launch_f16s<2, 4, 32, 32, 2, 1, false, 2, false>("conv3d_s1_f16s_co32", a, s);
 }
 
