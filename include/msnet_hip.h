@@ -88,6 +88,16 @@ int    msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, int Wb, in
                           msnet_stream_t stream);
 size_t msnet_build_volume_workspace_bytes(int Hb, int Wb, int ndisp);
 
+/* ---- test-time pre-processing: src/dataloader/cbmv_generator.py:780-788 (pad top/right to a multiple of
+ *      encoder_ds), :465-482 (down_sampling_input = skimage rescale by 1/ds with anti-aliasing, x255 -> uint8), :819-823
+ *      (`border`-pixel zero border).  img: u8[h][w] grayscale; out: u8[Hb][Wb] with the shape from
+ *      msnet_preprocess_out_shape; workspace: >= 4 bytes of device memory; taps_host: the 2*int(4*sigma+0.5)+1 gaussian
+ *      taps for sigma = (ds-1)/2 as scipy.ndimage computes them (host pointer), or NULL to compute them with libm.
+ *      ds = 1 copies.  The rescale restates skimage.transform.resize (parity unpinned: scikit-image is not available). */
+int msnet_preprocess_out_shape(int h, int w, int encoder_ds, int ds, int border, int* Hb, int* Wb);
+int msnet_preprocess_image(const uint8_t* img, int h, int w, int encoder_ds, int ds, int border,
+                           const double* taps_host, uint8_t* out, void* workspace, msnet_stream_t stream);
+
 /* ---- aggregator building blocks: replace the torch.nn calls inside
  *      src/models/gcnet_3dcnn.py:20-27,97-141 and src/models/psmnet_3dcnn.py:22-25,69-89,126-179 */
 int msnet_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, int D, int H, int W,

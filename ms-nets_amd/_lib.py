@@ -37,6 +37,8 @@ SIGNATURES = {
     "msnet_volume_default_params": (None, [ctypes.POINTER(VolumeParams)]),
     "msnet_build_volume": (c_int, [P, P, c_int, c_int, c_int, ctypes.POINTER(VolumeParams), P, P, P]),
     "msnet_build_volume_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "msnet_preprocess_out_shape": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "msnet_preprocess_image": (c_int, [P, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_double), P, P, P]),
     "msnet_ncdhw_to_ndhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_ndhwc_to_ncdhw": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_packed_weight_floats": (c_size_t, [c_int, c_int]),

@@ -95,3 +95,72 @@ def build_ms_volume(imgl_board, imgr_board, ndisp, params=None):
     vb = VolumeBuilder(imgl_board.shape[0], imgl_board.shape[1], ndisp, imgl_board.device, params)
     out = vb(imgl_board, imgr_board)
     return out.cpu().numpy() if was_numpy else out
+
+
+# ---- test-time pre-processing on the device -------------------------------------------------------------
+def _gaussian_taps(ds):
+    """The anti-aliasing taps exactly as scipy.ndimage._gaussian_kernel1d builds them for sigma = (ds-1)/2, truncate 4."""
+    sigma = (ds - 1) / 2.0
+    radius = int(4.0 * sigma + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return np.ascontiguousarray(phi / phi.sum(), dtype=np.float64)
+
+
+def prepare_test_image(img, encoder_ds=32, ds=2, board=10):
+    """generate_test_cbmv's image preparation (cbmv_generator.py:780-788, 811-812, 819-823) for one grayscale uint8
+    image [h, w] (NumPy or GPU tensor): pad top/right to a multiple of `encoder_ds`, rescale by 1/ds with
+    anti-aliasing (down_sampling_input), add a `board`-pixel zero border.  Returns a GPU uint8 tensor [Hb, Wb]."""
+    lib = _lib.load()
+    if isinstance(img, np.ndarray):
+        if img.dtype != np.uint8 or img.ndim != 2:
+            raise TypeError("img must be a 2-D uint8 array")
+        if not torch.cuda.is_available():
+            raise RuntimeError("prepare_test_image (HIP): no MI355X device visible and there is no CPU fallback")
+        img = torch.from_numpy(np.ascontiguousarray(img)).cuda()
+    img = _lib.require_gpu_f32(img, "img", torch.uint8)
+    if img.dim() != 2:
+        raise ValueError("img must be [h, w]")
+    h, w = int(img.shape[0]), int(img.shape[1])
+    hb, wb = ctypes.c_int(0), ctypes.c_int(0)
+    check(lib.msnet_preprocess_out_shape(h, w, int(encoder_ds), int(ds), int(board), ctypes.byref(hb), ctypes.byref(wb)),
+          "msnet_preprocess_out_shape")
+    out = torch.empty((hb.value, wb.value), device=img.device, dtype=torch.uint8)
+    ws = torch.empty(4, device=img.device, dtype=torch.uint8)
+    taps = _gaussian_taps(int(ds)) if int(ds) > 1 else np.ones(1, np.float64)
+    check(lib.msnet_preprocess_image(ptr(img), h, w, int(encoder_ds), int(ds), int(board),
+                                     taps.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ptr(out), ptr(ws), stream_ptr()),
+          "msnet_preprocess_image")
+    return out
+
+
+def down_sampling_input(ds_scale, imgl, imgr, anti_aliasing=True, multichannel=False, preserve_range=True):
+    """cbmv_generator.py:465-482 on the device: both images rescaled by `ds_scale` (= 1/integer).  NumPy in, NumPy out,
+    like the reference; GPU tensors in, GPU tensors out."""
+    if not anti_aliasing or multichannel or not preserve_range:
+        raise NotImplementedError("only the reference's own call (anti_aliasing, single channel, preserve_range) is built")
+    ds = int(round(1.0 / float(ds_scale)))
+    if ds < 1 or abs(ds * float(ds_scale) - 1.0) > 1e-9:
+        raise ValueError("ds_scale must be 1/integer")
+    outs = []
+    for im in (imgl, imgr):
+        if im.shape[0] % ds or im.shape[1] % ds:
+            raise ValueError("image size %s is not a multiple of %d (the reference pads to encoder_ds first)" % (tuple(im.shape), ds))
+        was_numpy = isinstance(im, np.ndarray)
+        o = prepare_test_image(im, encoder_ds=ds, ds=ds, board=0)
+        outs.append(o.cpu().numpy() if was_numpy else o)
+    return outs[0], outs[1]
+
+
+def generate_test_cbmv_from_images(imgl, imgr, encoder_ds=32, maxdisp=192, args_dict=None):
+    """generate_test_cbmv (cbmv_generator.py:726-845) from already-decoded grayscale images, left features only:
+    pre-processing and the 8-channel volume on the device.  Returns (features [8, D', H', W'] GPU tensor, (pad_h, pad_w))."""
+    args = get_default_args_dict() if args_dict is None else args_dict
+    ds = int(args.get("ds_scale", 2))
+    h, w = int(imgl.shape[0]), int(imgl.shape[1])
+    lb = prepare_test_image(imgl, encoder_ds, ds, 10)
+    rb = prepare_test_image(imgr, encoder_ds, ds, 10)
+    params = dict(censw=args["censw"], nccw=args["nccw"], sadw=args["sadw"], sobelw=args["sobelw"],
+                  cens_sigma=args["cens_sigma"], ncc_sigma=args["ncc_sigma"], sad_sigma=args["sad_sigma"])
+    vol = build_ms_volume(lb, rb, maxdisp // ds, params=params)
+    return vol, ((encoder_ds - h % encoder_ds) % encoder_ds, (encoder_ds - w % encoder_ds) % encoder_ds)

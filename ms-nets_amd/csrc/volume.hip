@@ -566,6 +566,78 @@ __global__ __launch_bounds__(256) void features_all_kernel(FusedArgs a) {
     }
 }
 
+// ---------------------------------------------------------------- test-time pre-processing ------------
+// cbmv_generator.py:780-788 (pad top/right to a multiple of encoder_ds), :465-482 (x 1/s rescale with anti-aliasing) and
+// :819-823 (zero border), one thread per output pixel of the bordered image.  The rescale is skimage.transform.resize as
+// restated in oracle/ms_volume.py (rescale_explicit): gaussian_filter(sigma=(s-1)/2, mode constant) = two separable
+// passes in scipy's correlate1d order with double accumulation and float32 between the passes, then the mean of the two
+// central source pixels per axis (even s) or the centre pixel (odd s), clip to [0, max], x255, truncate.
+struct PrepArgs {
+    const uint8_t* img; uint8_t* out; const unsigned* vmax_u8;
+    int h, w, pad_h, Hp, Wp, s, r, border, Ho, Wo;       // Ho, Wo: rescaled size without the border
+    double wt[32];                                       // gaussian taps, centre at wt[r]
+};
+
+__global__ void image_max_kernel(const uint8_t* __restrict__ img, size_t n, unsigned* __restrict__ out) {
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        m = max(m, (unsigned)img[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+__device__ __forceinline__ float prep_pixel(const PrepArgs& a, int y, int x) {       // padded image / 255, zero outside
+    if ((unsigned)y >= (unsigned)a.Hp || (unsigned)x >= (unsigned)a.w || y < a.pad_h) return 0.f;
+    return (float)a.img[(size_t)(y - a.pad_h) * a.w + x] / 255.0f;
+}
+__device__ __forceinline__ float prep_vertical(const PrepArgs& a, int y, int x) {    // first pass (axis 0), float32 result
+    if ((unsigned)x >= (unsigned)a.Wp) return 0.f;                                   // second pass pads with zeros
+    double t = (double)prep_pixel(a, y, x) * a.wt[a.r];
+    for (int j = -a.r; j < 0; ++j) {
+        const double sum = (double)prep_pixel(a, y + j, x) + (double)prep_pixel(a, y - j, x);
+        t = t + sum * a.wt[a.r + j];
+    }
+    return (float)t;
+}
+__device__ __forceinline__ float prep_filtered(const PrepArgs& a, int y, int x) {    // second pass (axis 1)
+    double t = (double)prep_vertical(a, y, x) * a.wt[a.r];
+    for (int j = -a.r; j < 0; ++j) {
+        const double sum = (double)prep_vertical(a, y, x + j) + (double)prep_vertical(a, y, x - j);
+        t = t + sum * a.wt[a.r + j];
+    }
+    return (float)t;
+}
+
+__global__ void preprocess_kernel(PrepArgs a) {
+    const int xo = blockIdx.x * blockDim.x + threadIdx.x, yo = blockIdx.y;
+    const int Wb = a.Wo + 2 * a.border;
+    if (xo >= Wb) return;
+    const int oy = yo - a.border, ox = xo - a.border;
+    uint8_t v = 0;
+    if ((unsigned)oy < (unsigned)a.Ho && (unsigned)ox < (unsigned)a.Wo) {
+        if (a.s == 1) {
+            v = (oy >= a.pad_h && ox < a.w) ? a.img[(size_t)(oy - a.pad_h) * a.w + ox] : 0;
+        } else {
+            const int lo = (a.s - 1) / 2, y0 = oy * a.s + lo, x0 = ox * a.s + lo;
+            float o;
+            if (a.s % 2 == 0) {
+                double acc = 0.0;
+                for (int dy = 0; dy < 2; ++dy) {
+                    const double t = 0.25 * (double)prep_filtered(a, y0 + dy, x0) + 0.25 * (double)prep_filtered(a, y0 + dy, x0 + 1);
+                    acc = acc + t;
+                }
+                o = (float)acc;
+            } else {
+                o = prep_filtered(a, y0, x0);
+            }
+            const float vmax = (float)(*a.vmax_u8) / 255.0f;
+            o = fminf(fmaxf(o, 0.f), vmax);
+            v = (uint8_t)(o * 255.0f);
+        }
+    }
+    a.out[(size_t)yo * Wb + xo] = v;
+}
+
 static inline int grid1d(size_t total, int cap = 16384) {
     const size_t b = (total + 255) / 256;
     return (int)(b < (size_t)cap ? (b ? b : 1) : cap);
@@ -784,4 +856,43 @@ extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, in
             hipLaunchKernelGGL((features_all_kernel<0, 0, 0, 0>), gf, dim3(256), 0, s, a);
     }
     return check_launch("msnet_build_volume");
+}
+
+extern "C" int msnet_preprocess_out_shape(int h, int w, int encoder_ds, int ds, int border, int* Hb, int* Wb) {
+    if (h <= 0 || w <= 0 || encoder_ds <= 0 || ds <= 0 || border < 0 || encoder_ds % ds != 0)
+        return fail("msnet_preprocess_out_shape: bad arguments (h=%d w=%d encoder_ds=%d ds=%d border=%d)", h, w, encoder_ds, ds, border);
+    const int Hp = h + (encoder_ds - h % encoder_ds) % encoder_ds, Wp = w + (encoder_ds - w % encoder_ds) % encoder_ds;
+    if (Hb) *Hb = Hp / ds + 2 * border;
+    if (Wb) *Wb = Wp / ds + 2 * border;
+    return 0;
+}
+
+extern "C" int msnet_preprocess_image(const uint8_t* img, int h, int w, int encoder_ds, int ds, int border,
+                                      const double* taps_host, uint8_t* out, void* workspace, msnet_stream_t stream) {
+    if (!img || !out || !workspace) return fail("msnet_preprocess_image: null pointer");
+    int Hb = 0, Wb = 0;
+    if (int e = msnet_preprocess_out_shape(h, w, encoder_ds, ds, border, &Hb, &Wb)) return e;
+    if (ds > 8) return fail("msnet_preprocess_image: ds=%d (at most 8: the gaussian has 4*(ds-1)+1 <= 29 taps)", ds);
+    PrepArgs a{};
+    a.img = img; a.out = out; a.vmax_u8 = (const unsigned*)workspace;
+    a.h = h; a.w = w;
+    a.Hp = h + (encoder_ds - h % encoder_ds) % encoder_ds; a.Wp = w + (encoder_ds - w % encoder_ds) % encoder_ds;
+    a.pad_h = a.Hp - h; a.s = ds; a.border = border; a.Ho = a.Hp / ds; a.Wo = a.Wp / ds;
+    const double sigma = (ds - 1) / 2.0;
+    a.r = (int)(4.0 * sigma + 0.5);
+    if (ds == 1) { a.r = 0; a.wt[0] = 1.0; }
+    else if (taps_host) {                               // the caller's 2r+1 taps (the Python mirror passes scipy's, bit for bit)
+        for (int k = 0; k <= 2 * a.r; ++k) a.wt[k] = taps_host[k];
+    } else {                                            // same formula in libm; may differ from NumPy's in the last ulp
+        double sum = 0.0;
+        for (int k = -a.r; k <= a.r; ++k) a.wt[a.r + k] = exp(-0.5 / (sigma * sigma) * (double)(k * k));
+        for (int k = 0; k <= 2 * a.r; ++k) sum += a.wt[k];
+        for (int k = 0; k <= 2 * a.r; ++k) a.wt[k] /= sum;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    LaunchScope ls("preprocess", s, 0, (double)h * w + (double)Hb * Wb);
+    if (hipMemsetAsync(workspace, 0, 4, s) != hipSuccess) return fail("msnet_preprocess_image: memset failed");
+    hipLaunchKernelGGL(image_max_kernel, dim3(64), dim3(256), 0, s, img, (size_t)h * w, (unsigned*)workspace);
+    hipLaunchKernelGGL(preprocess_kernel, dim3(cdiv(Wb, 64), Hb), dim3(64), 0, s, a);
+    return check_launch("msnet_preprocess_image");
 }

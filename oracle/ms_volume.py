@@ -147,3 +147,93 @@ def build_ms_volume(imgl_board, imgr_board, ndisp, board=10):
     down-sampled, bordered uint8 images: get_costs(..., 11,3,5,5, 10,10,10) -> extract_features_left."""
     c, n, so, sa = get_costs(imgl_board, imgr_board, ndisp, 11, 3, 5, 5, board, board, board)
     return extract_features_left(c, n, so, sa, 128.0, 0.02, 20000.0, 20000.0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Test-time pre-processing (SURVEY section 8(f).1): cbmv_generator.py:780-788 (pad to a multiple of encoder_ds on the
+# TOP and RIGHT), :465-482 (down_sampling_input = skimage.transform.rescale(img/255, 1/s, anti_aliasing=True,
+# mode='constant', preserve_range=True) * 255 -> uint8) and :819-823 (10-px zero border).
+#
+# PARITY UNPINNED for the rescale: scikit-image is not installed here and the reference holds no vectors for it.  The
+# restatement below follows skimage.transform.resize as published (0.16-0.19): anti-aliasing = scipy.ndimage
+# gaussian_filter with sigma = (s-1)/2, mode='constant', cval=0 (truncate 4.0), then an order-1 resample at the
+# pixel-centre-aligned coordinates (x + 0.5)*s - 0.5 (for integer s: the mean of the two central source pixels per
+# axis, or the centre pixel for odd s), then clipping to the input's value range (cval included).  Two forms:
+#   rescale_scipy  : literally those scipy.ndimage calls (gaussian_filter + zoom(order=1, grid_mode=True))
+#   rescale_explicit: the same arithmetic spelled out (double accumulation in scipy's correlate1d order, float32
+#                     between passes) -- what the HIP kernel implements; tests require the two to agree bit for bit.
+# ---------------------------------------------------------------------------------------------------------------
+def gaussian_weights(s):
+    """scipy.ndimage._gaussian_kernel1d(sigma=(s-1)/2, order 0, radius=int(4*sigma+0.5)) in double."""
+    sigma = (s - 1) / 2.0
+    radius = int(4.0 * sigma + 0.5)
+    if sigma <= 0:
+        return np.ones(1, np.float64)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return phi / phi.sum()
+
+
+def _correlate_sym(a, w, axis):
+    """scipy ni_filters.c NI_Correlate1D, symmetric branch, mode='constant' cval 0, float32 output:
+    tmp = x[0]*w[c]; for j = -r..-1: tmp += (x[j] + x[-j]) * w[c+j]   (all in double)."""
+    r = len(w) // 2
+    a64 = np.moveaxis(a.astype(np.float64), axis, -1)
+    pad = np.zeros(a64.shape[:-1] + (r,), np.float64)
+    p = np.concatenate([pad, a64, pad], axis=-1)
+    n = a64.shape[-1]
+    tmp = p[..., r:r + n] * w[r]
+    for j in range(-r, 0):
+        tmp = tmp + (p[..., r + j:r + j + n] + p[..., r - j:r - j + n]) * w[r + j]
+    return np.moveaxis(tmp.astype(np.float32), -1, axis)
+
+
+def rescale_explicit(img_u8, s):
+    """uint8 [H, W] (H, W multiples of s) -> uint8 [H/s, W/s], see the block comment above."""
+    s = int(s)
+    img_u8 = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    if s == 1:
+        return img_u8.copy()
+    H, W = img_u8.shape
+    assert H % s == 0 and W % s == 0
+    x = img_u8.astype(np.float32) / np.float32(255.0)
+    w = gaussian_weights(s)
+    f = _correlate_sym(_correlate_sym(x, w, 0), w, 1)           # gaussian_filter: axis 0 then axis 1
+    lo = (s - 1) // 2                                           # floor((x+0.5)*s - 0.5) - x*s
+    if s % 2 == 0:                                              # half-integer coordinate: mean of two pixels per axis
+        f64 = f.astype(np.float64)
+        rows = [f64[lo::s], f64[lo + 1::s]]
+        acc = np.zeros((H // s, W // s), np.float64)
+        for rr in rows:
+            acc += 0.25 * rr[:, lo::s] + 0.25 * rr[:, lo + 1::s]
+        out = acc.astype(np.float32)
+    else:
+        out = f[lo::s, lo::s].copy()
+    vmax = np.float32(x.max())
+    out = np.minimum(np.maximum(out, np.float32(0.0)), vmax)    # _clip_warp_output (cval = 0 joins the range)
+    return (out * np.float32(255.0)).astype(np.uint8)
+
+
+def rescale_scipy(img_u8, s):
+    from scipy import ndimage as ndi
+    s = int(s)
+    if s == 1:
+        return np.ascontiguousarray(img_u8, dtype=np.uint8).copy()
+    x = np.ascontiguousarray(img_u8, dtype=np.uint8).astype(np.float32) / np.float32(255.0)
+    sigma = (s - 1) / 2.0
+    f = ndi.gaussian_filter(x, (sigma, sigma), cval=0, mode="constant")
+    out = ndi.zoom(f, (1.0 / s, 1.0 / s), order=1, mode="grid-constant", cval=0, grid_mode=True)
+    out = np.clip(out, min(float(x.min()), 0.0), float(x.max())).astype(np.float32)
+    return (out * np.float32(255.0)).astype(np.uint8)
+
+
+def prepare_test_image(img_u8, encoder_ds=32, ds=2, board=10):
+    """cbmv_generator.py:780-788 + :811-812 + :819-823 for one grayscale image: pad (top, right) to a multiple of
+    encoder_ds, rescale by 1/ds, add a `board`-pixel zero border."""
+    img_u8 = np.ascontiguousarray(img_u8, dtype=np.uint8)
+    h, w = img_u8.shape
+    pad_w = (encoder_ds - w % encoder_ds) % encoder_ds
+    pad_h = (encoder_ds - h % encoder_ds) % encoder_ds
+    p = np.pad(img_u8, ((pad_h, 0), (0, pad_w)), "constant")
+    p = rescale_explicit(p, ds)
+    return np.pad(p, ((board, board), (board, board)), "constant").astype(np.uint8).copy(order="C")
