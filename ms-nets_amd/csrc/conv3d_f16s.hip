@@ -112,8 +112,13 @@ __global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* _
 // RESB = true: all 27 taps of the (single-chunk) weight tensor stay resident in LDS for the whole kernel -- used when
 //               they fit beside the tile (the 8-channel layer: 54 KB): no weight streaming, 2 barriers per item instead of 10.
 // STRIDE = 1 or 2 (stride 2: the input tile is (2T+1)^3, so it is staged 16 channels at a time, KS = 1).
-template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB, int STRIDE>
+// SLIDE (single-chunk stride-1 layers): a workgroup walks a column of tiles along d, so consecutive tiles share two of
+// their four input planes.  The LDS plane slots rotate by two per step (logical plane p of step j lives in slot
+// (p + 2j) & 3); only the two new planes are fetched, split and copied -- into the slots of the two planes that die
+// first -- and the two-barrier staging window between tiles is empty except at the start of a column.
+template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB, int STRIDE, bool SLIDE = false>
 __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
+    static_assert(!SLIDE || (STRIDE == 1 && !RESB && !SWZ && TD == 2), "sliding window: stride 1, streamed weights, padded records");
     constexpr int CC = 16 * KS;
     constexpr int BH = 32 / BW;
     constexpr int ID = (TD - 1) * STRIDE + 3, IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
@@ -143,30 +148,34 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     const unsigned lb = xcd_remap(blockIdx.x, G);
     const int nchunks = a.Ci < CC ? 1 : a.Ci / CC;
     const int ncg = a.ngroups;                          // output-channel groups of 32*NB channels
-    const unsigned T = (unsigned)a.N * a.ntd * a.nth * a.ntw * ncg;
+    // work units dealt to the workgroups: tiles (x nchunks items each), or for SLIDE column segments (x seglen items each)
+    const int per_unit = SLIDE ? a.seglen : nchunks;
+    const unsigned T = SLIDE ? (unsigned)a.N * a.nseg * a.nth * a.ntw * ncg : (unsigned)a.N * a.ntd * a.nth * a.ntw * ncg;
     const int my_tiles = (T > lb) ? (int)((T - lb + G - 1) / G) : 0;
-    const int nitems = my_tiles * nchunks;
+    const int nitems = my_tiles * per_unit;
     if (nitems == 0) return;
     const u32x4* wg = reinterpret_cast<const u32x4*>(a.wpk);     // split-fp16 packed weights
 
     auto decode_g = [&](int it, int& n, int& od0, int& oh0, int& ow0, int& chunk, int& cg) {
-        unsigned t = lb + (unsigned)(it / nchunks) * G;
-        chunk = it % nchunks;
+        unsigned t = lb + (unsigned)(it / per_unit) * G;
+        chunk = SLIDE ? 0 : it % nchunks;
         cg = t % ncg; t /= ncg;
         ow0 = (t % a.ntw) * TW; t /= a.ntw;
         oh0 = (t % a.nth) * TH; t /= a.nth;
-        od0 = (t % a.ntd) * TD;
-        n = t / a.ntd;
+        if (SLIDE) {
+            od0 = ((t % a.nseg) * a.seglen + it % a.seglen) * TD;
+            n = t / a.nseg;
+        } else {
+            od0 = (t % a.ntd) * TD;
+            n = t / a.ntd;
+        }
     };
     auto decode = [&](int it, int& n, int& od0, int& oh0, int& ow0, int& chunk) {
-        unsigned t = lb + (unsigned)(it / nchunks) * G;
-        chunk = it % nchunks;
-        t /= ncg;
-        ow0 = (t % a.ntw) * TW; t /= a.ntw;
-        oh0 = (t % a.nth) * TH; t /= a.nth;
-        od0 = (t % a.ntd) * TD;
-        n = t / a.ntd;
+        int cg_;
+        decode_g(it, n, od0, oh0, ow0, chunk, cg_);
     };
+    // SLIDE: item `it` continues the column of item it-1 iff it is not the first of its segment
+    auto continues = [&](int it) { return SLIDE && it > 0 && (it % per_unit) != 0; };
 
     if (wave >= 4) {
         // ------------------------------ loader waves ------------------------------
@@ -244,7 +253,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
                 av[pl][u] = __builtin_bit_cast(f32x4, raw);
             }
         };
-        // split + copy slots [u0, u1) of plane pl into LDS
+        // split + copy slots [u0, u1) of plane pl into LDS (SLIDE: into plane slot (pl + 2*wrot) & 3)
+        int wrot = 0;
         auto write_a = [&](int pl, int u0, int u1) {
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
@@ -260,7 +270,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
 #else
                     split4(av[pl][u], hi, lo);
 #endif
-                    const int off = lhi_[pl] + u * (256 / VR) * RB;
+                    const int off = (SLIDE ? lhi_[0] + ((pl + 2 * wrot) & 3) * (IH * IW * RB) : lhi_[pl]) + u * (256 / VR) * RB;
                     *reinterpret_cast<half4*>(lds + off) = hi;
                     *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ 64) : off + HB)) = lo;
                 }
@@ -273,8 +283,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         auto b_src = [&](int k) {
             k = k < ngroups_total ? k : ngroups_total - 1;     // past the end: harmless re-read
             const int it_ = k / 9;
-            const unsigned cg = ncg == 1 ? 0u : (lb + (unsigned)(it_ / nchunks) * G) % (unsigned)ncg;
-            return wg + (size_t)((cg * nchunks + (it_ % nchunks)) * 9 + (k % 9)) * PG;
+            const unsigned cg = ncg == 1 ? 0u : (lb + (unsigned)(it_ / per_unit) * G) % (unsigned)ncg;
+            return wg + (size_t)((cg * nchunks + (SLIDE ? 0 : it_ % nchunks)) * 9 + (k % 9)) * PG;
         };
         // piece index of this thread's u-th piece (clamped for the partial last piece of a 384-piece group)
         int bi_[3];
@@ -343,6 +353,50 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         MSNET_ISSUE_B(0, bw0);
         MSNET_ISSUE_B(1, bw1);
         MSNET_ISSUE_B(2, bw2);
+        if constexpr (SLIDE) {
+            constexpr int H0 = (PL + 2) / 3, H1 = (2 * PL + 2) / 3, HH = (PL + 1) / 2;
+            bool early = false;                         // planes 0,1 of this column-start item were copied during the previous item
+            int rot = 0;                                // plane-slot rotation of the current item
+            [[maybe_unused]] int sidx = 0;
+            for (int it = 0; it < nitems; ++it) {
+                const int k0 = it * 9;
+                const bool more = it + 1 < nitems;
+                const bool cs = !continues(it);         // the current item starts a column: its planes 2,3 (0,1) are not resident
+                if (!cs) rot ^= 1;
+                const bool ncont = more && continues(it + 1);
+                MSNET_LDS_BARRIER();                    // b1: MFMA waves are done with the previous tile
+                wrot = rot;
+                if (cs) {
+                    if (!early) { write_a(0, 0, PL); write_a(1, 0, PL); }
+                    write_a(2, 0, PL); write_a(3, 0, PL);
+                }
+                MSNET_WRITE_B(k0, bw0);
+                MSNET_ISSUE_B(k0 + 3, bw0);
+                MSNET_LDS_BARRIER();                    // b2: tile and group 0 are in LDS
+                // Next item: a continuation needs only its logical planes 2,3 (into the slots of this item's planes 0,1, dead
+                // after groups 2 / 5); a column start needs all four (0,1 into those slots, 2,3 in its own b1/b2 window).
+                Coord nx = coord_of(more ? it + 1 : it);
+                wrot = ncont ? rot ^ 1 : rot;
+                if (more) { if (ncont) issue_a(nx, 2, 0, PL); else { issue_a(nx, 0, 0, PL); issue_a(nx, 1, 0, HH); } }
+                MSNET_GROUP(0, bw1)
+                if (more) { if (ncont) issue_a(nx, 3, 0, PL); else { issue_a(nx, 1, HH, PL); issue_a(nx, 2, 0, PL); } }
+                MSNET_GROUP(1, bw2)
+                if (more && !ncont) issue_a(nx, 3, 0, PL);
+                MSNET_GROUP(2, bw0)                     // g_2 passed: this item's logical plane 0 is dead
+                if (more) { if (ncont) write_a(2, 0, H0); else write_a(0, 0, H0); }
+                MSNET_GROUP(3, bw1)
+                if (more) { if (ncont) write_a(2, H0, H1); else write_a(0, H0, H1); }
+                MSNET_GROUP(4, bw2)
+                if (more) { if (ncont) write_a(2, H1, PL); else write_a(0, H1, PL); }
+                MSNET_GROUP(5, bw0)                     // g_5 passed: logical plane 1 is dead
+                if (more) { if (ncont) write_a(3, 0, HH); else write_a(1, 0, HH); }
+                MSNET_GROUP(6, bw1)
+                if (more) { if (ncont) write_a(3, HH, PL); else write_a(1, HH, PL); }
+                MSNET_GROUP(7, bw2)
+                early = more && !ncont;
+            }
+            return;
+        }
         bool early = false;                             // planes 0,1 of this item already copied during the previous one
         int sidx = 0;
         // The loader shares each SIMD with an MFMA wave and runs ~3x slower than alone, so its per-item work (28 loads,
@@ -417,8 +471,17 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         const int mb = wm * MB + i;
         const int bw_ = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
         const int lh = bh * BH + r / BW, lw = bw_ * BW + r % BW;
-        vox0[i] = (bd * STRIDE * IH + lh * STRIDE) * IW + lw * STRIDE;
+        vox0[i] = ((SLIDE ? 0 : bd * STRIDE * IH) + lh * STRIDE) * IW + lw * STRIDE;    // SLIDE: the plane comes from grp_off
     }
+    int rot = 0;                                        // SLIDE: plane-slot rotation of the current item
+    // voxel offset of group g's (kd, kh) row for M-block i
+    auto grp_off = [&](int g, int i) {
+        if (SLIDE) {
+            const int bd = (wm * MB + i) / (MW * MH);
+            return ((((bd + g / 3 + 2 * rot) & 3) * IH) + g % 3) * IW;
+        }
+        return ((g / 3) * IH + (g % 3)) * IW;
+    };
     const int stride_w = a.Co, stride_h = a.OW * a.Co;
 
     f32x16 acc0[MB][NB], acc1[MB][NB];
@@ -453,6 +516,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     for (int it = 0; it < nitems; ++it) {
         int n, od0, oh0, ow0, chunk, cg;
         decode_g(it, n, od0, oh0, ow0, chunk, cg);
+        if (continues(it)) rot ^= 1;
         if (wave == 0) STAMP(0, sidx, lane);
         MSNET_LDS_BARRIER();                            // b1
         if (wave == 0) STAMP(0, sidx, lane);
@@ -480,10 +544,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         constexpr int PF = R - 1;
         static_assert(NS % R == 0 && PF <= NS, "fragment ring must tile the group");
         half8 ah[R][MB], al[R][MB], bh_[R][NB], bl[R][NB];
-        auto frag_a = [&](int s, int slot, int goff) {    // goff: voxel offset of the group's (kd, kh) row
+        auto frag_a = [&](int s, int slot, const int (&goffs)[MB]) {    // goffs[i]: voxel offset of the group's (kd, kh) row
             const int t = s / KS, ks = s % KS;
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
+                const int goff = goffs[i];
                 if (SWZ) {
                     const int vox = vox0[i] + goff + t;
                     const int off = vox * RB + (((ks * 2 + hh) ^ ((vox >> 1) & 7)) << 4);
@@ -505,13 +570,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
                 bl[slot][j] = *reinterpret_cast<const half8*>(p + 1024);
             }
         };
+        int goff[MB], goff_next[MB];
 #pragma unroll
-        for (int q = 0; q < PF; ++q) frag_a(q, q, 0);
+        for (int i = 0; i < MB; ++i) goff_next[i] = grp_off(0, i);
+#pragma unroll
+        for (int q = 0; q < PF; ++q) frag_a(q, q, goff_next);
 #pragma unroll 1
         for (int g = 0; g < 9; ++g) {
             const unsigned char* bb = lds_b + (RESB ? g : ((gg0 + g) & 1)) * GB + lane * 16;
-            const int goff = ((g / 3) * IH + (g % 3)) * IW;              // (kd, kh) row of this group, in voxels
-            const int goff_next = (((g + 1) / 3) * IH + ((g + 1) % 3)) * IW;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) { goff[i] = goff_next[i]; goff_next[i] = grp_off(g + 1, i); }   // (kd, kh) rows, in voxels
 #pragma unroll
             for (int q = 0; q < PF; ++q) frag_b(q, q, bb);
 #pragma unroll
@@ -1084,6 +1152,43 @@ static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     return check_launch(name);
 }
 
+// Sliding-window launch for single-chunk stride-1 layers.  A tile column (all d at one (h, w) tile) is cut into `nseg`
+// segments that are dealt to the persistent workgroups; within a segment every tile after the first stages two planes
+// instead of four (modelled as 0.8 of a tile), so longer segments are cheaper per tile but balance worse.  Returns -1
+// when plain tiles are estimated to be no slower (the caller then launches the ordinary kernel).
+template <int TH, int TW, int MB, int NB>
+static int launch_f16s_slide(const char* name, ConvArgs a, hipStream_t s) {
+    constexpr int TD = 2;
+    a.ntd = cdiv(a.OD, TD); a.nth = cdiv(a.OH, TH); a.ntw = cdiv(a.OW, TW);
+    a.ngroups = a.Co / (32 * NB); a.nbtot = a.Co / 32;
+    const size_t cols = (size_t)a.N * a.nth * a.ntw * a.ngroups;
+    if (cols == 0 || cols * a.ntd > 0x7fffffffu) return fail("%s: bad tile count", name);
+    const double G = (double)num_cus();
+    double best = ceil((double)cols * a.ntd / G);       // plain tiles, one unit of time each
+    int best_seg = 0;
+    for (int seg = 1; seg <= a.ntd; ++seg) {
+        if (a.ntd % seg) continue;
+        const int len = a.ntd / seg;
+        if (len < 2) break;
+        const double cost = ceil((double)cols * seg / G) * (1.0 + 0.8 * (len - 1));
+        if (cost < 0.97 * best) { best = cost; best_seg = seg; }
+    }
+    if (const char* e = getenv("MSNET_FORCE_SLIDE_SEG")) {     // test hook: force the sliding kernel with this many segments
+        const int seg = atoi(e);
+        if (seg >= 1 && a.ntd % seg == 0 && a.ntd / seg >= 2) best_seg = seg;
+        else if (seg == 0) best_seg = 0;
+    }
+    if (!best_seg) return -1;
+    a.nseg = best_seg; a.seglen = a.ntd / best_seg;
+    const size_t units = cols * a.nseg;
+    const size_t nblk = units < (size_t)num_cus() ? units : (size_t)num_cus();
+    const double vox = (double)a.N * a.OD * a.OH * a.OW;
+    LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
+                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
+    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, 32, MB, NB, false, 2, false, 1, true>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+    return check_launch(name);
+}
+
 }  // namespace msnet
 
 using namespace msnet;
@@ -1149,6 +1254,10 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
         return launch_f16s<2, 4, 32, 32, 2, 2, true, 2, false>("conv3d_s1_f16s_co64", a, s);
     }
     // (2x8x16 tiles and swizzled 128-byte records were measured for this layer too: both 4 % slower than padded 2x4x32)
+    if (Ci == 32) {                                     // single 32-channel chunk: sliding window along d
+        const int rc = launch_f16s_slide<4, 32, 2, 1>("conv3d_s1_f16s_co32", a, s);
+        if (rc >= 0) return rc;
+    }
     return launch_f16s<2, 4, 32, 32, 2, 1, false, 2, false>("conv3d_s1_f16s_co32", a, s);
 }
 

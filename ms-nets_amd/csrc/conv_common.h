@@ -29,6 +29,7 @@ struct ConvArgs {
     int ntd, nth, ntw;     // tiles per dim (conv: over output dims; deconv: over input dims)
     int ngroups;           // Co / (32 * WN * NB)
     int nbtot;             // Co / 32
+    int nseg, seglen;      // sliding-window kernels: depth segments per tile column, tiles (depth steps) per segment
 };
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {

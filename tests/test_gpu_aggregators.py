@@ -127,6 +127,35 @@ def test_conv3d_layer_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res):
     assert err < 5e-6
 
 
+@pytest.mark.parametrize("dims,seg", [((1, 12, 9, 70), 1), ((1, 12, 9, 70), 3), ((2, 8, 16, 33), 2), ((1, 16, 5, 32), 4),
+                                      ((1, 6, 4, 32), 1)])
+@pytest.mark.parametrize("use_res", [False, True])
+def test_conv3d_sliding_window_kernel(gpu, hiplib, monkeypatch, dims, seg, use_res):
+    """The sliding-window variant of the 32->32 kernel (plane slots rotate along d) is normally chosen only for large
+    volumes; MSNET_FORCE_SLIDE_SEG forces it with a given number of segments per tile column.  Same bar as the plain kernel,
+    and bit-identical to it (same MFMA sequence per output)."""
+    from msnets_amd import hipops
+    g = torch.Generator().manual_seed(sum(dims) + seg)
+    n, d, h, w = dims
+    x = torch.randn((n, 32, d, h, w), generator=g) * 3
+    wt = torch.randn((32, 32, 3, 3, 3), generator=g) * (2.0 / (27 * 32)) ** 0.5
+    shift = torch.randn(32, generator=g) * 0.1
+    ref = F.conv3d(x.double(), wt.double(), None, padding=1) + shift.double().view(1, -1, 1, 1, 1)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res.double()
+    ref = F.relu(ref)
+    wpk = hipops.pack_conv_weight(wt.cuda(), f16s=True)
+    run = lambda: hipops.conv3d_k3(_cl(x), wpk, None, shift.cuda(), 32, relu=True, residual=_cl(res) if use_res else None, f16s=True)
+    monkeypatch.setenv("MSNET_FORCE_SLIDE_SEG", "0")
+    plain = run()
+    monkeypatch.setenv("MSNET_FORCE_SLIDE_SEG", str(seg))
+    slid = run()
+    torch.cuda.synchronize()
+    assert _rel(_nc(slid).double(), ref) < 5e-6
+    assert torch.equal(plain, slid)
+
+
 @pytest.mark.parametrize("ci,co,stride,dims,relu,use_res", CONV_CASES)
 def test_conv3d_layer(gpu, ci, co, stride, dims, relu, use_res):
     from msnets_amd import hipops
