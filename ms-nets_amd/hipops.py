@@ -48,8 +48,8 @@ def pack_conv_weight(w, transposed=False, f16s=False, stride=1):
 
 PRECISIONS = ("fp32", "split-fp16")
 _default_precision = "split-fp16"
-# Transposed convs with a split-fp16 kernel (Ci = 64) use it: 1.22 vs 1.99 ms on deconvbn4, 0.28 vs 0.84 ms on deconvbn3
-# (profiles/r01l_*); the rest (deconvbn1, 128 -> 64 on a 6x17x30 grid) stay on the fp32 MFMA.
+# Transposed convs with a split-fp16 kernel use it: Ci = 64 on the tiled kernel (1.22 vs 1.99 ms on deconvbn4, 0.28 vs
+# 0.84 ms on deconvbn3, profiles/r01l_*), Ci = 32 / 128 and every small layer on the direct kernel (deconvbn1: 0.04 vs 0.14 ms).
 USE_F16S_DECONV = True
 
 

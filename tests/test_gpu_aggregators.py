@@ -77,9 +77,11 @@ F16S_S2_CASES = [(32, 64, (1, 8, 12, 34), True, False), (64, 64, (1, 6, 9, 33), 
 
 
 @pytest.mark.parametrize("ci,co,dims,relu,use_res", F16S_S2_CASES)
-def test_conv3d_stride2_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res):
+@pytest.mark.parametrize("direct", ["0", "1"])
+def test_conv3d_stride2_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res, direct, monkeypatch):
     from msnets_amd import hipops
     assert hiplib.msnet_conv3d_k3_f16s_supported(ci, co, 2) == 1
+    monkeypatch.setenv("MSNET_DIRECT", direct)      # "0": tiled persistent kernel, "1": direct small-layer kernel
     g = torch.Generator().manual_seed(ci * 7 + co)
     n, d, h, w = dims
     x = torch.randn((n, ci, d, h, w), generator=g) * 3
@@ -102,11 +104,13 @@ def test_conv3d_stride2_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res):
 
 
 @pytest.mark.parametrize("ci,co,dims,relu,use_res", F16S_CASES)
-def test_conv3d_layer_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res):
+@pytest.mark.parametrize("direct", ["0", "1"])
+def test_conv3d_layer_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res, direct, monkeypatch):
     """Split-fp16 MFMA path: operands carry 22 bits, so a single layer agrees with the fp64 conv to ~1e-6
     relative (plain fp16 operands would be ~5e-4)."""
     from msnets_amd import hipops
     assert hiplib.msnet_conv3d_k3_f16s_supported(ci, co, 1) == 1
+    monkeypatch.setenv("MSNET_DIRECT", direct)      # "0": tiled persistent kernel, "1": direct small-layer kernel
     g = torch.Generator().manual_seed(ci * 31 + co)
     n, d, h, w = dims
     x = torch.randn((n, ci, d, h, w), generator=g) * 3
@@ -212,10 +216,14 @@ def test_deconv3d_layer(gpu, ci, co, dims, relu, use_res):
 
 
 @pytest.mark.parametrize("ci,co,dims,relu,use_res", [(64, 32, (1, 4, 9, 17), True, True), (64, 32, (2, 3, 4, 32), False, True),
-                                                   (64, 64, (1, 4, 6, 20), True, True), (64, 64, (1, 3, 5, 33), True, False)])
-def test_deconv3d_layer_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res):
+                                                   (64, 64, (1, 4, 6, 20), True, True), (64, 64, (1, 3, 5, 33), True, False),
+                                                   (128, 64, (1, 3, 5, 14), True, True), (32, 32, (2, 2, 3, 9), False, False),
+                                                   (128, 96, (1, 2, 4, 7), True, False)])
+@pytest.mark.parametrize("direct", ["0", "1"])
+def test_deconv3d_layer_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res, direct, monkeypatch):
     from msnets_amd import hipops
     assert hiplib.msnet_deconv3d_k3s2_f16s_supported(ci, co) == 1
+    monkeypatch.setenv("MSNET_DIRECT", direct)      # "0": tiled persistent kernel, "1": direct small-layer kernel
     g = torch.Generator().manual_seed(ci * 13 + co)
     n, d, h, w = dims
     x = torch.randn((n, ci, d, h, w), generator=g) * 3
