@@ -207,8 +207,10 @@ __global__ __launch_bounds__(256) void deconv5_tail_mfma_kernel(const float* __r
                                                                 float bias, float* __restrict__ out, int N, int D, int H,
                                                                 int W, int nth, int ntw) {
     constexpr int CI = 32, TH = 8, TW = 32, UH = 7, UW = 31, PS = CI + 4, TS = 33, NT = 256;
+    // the tap partials reuse the slice buffer (its fragments are in registers by then): 37 KB per workgroup, so the
+    // register file, not LDS, sets the occupancy (three workgroups per CU instead of two: 0.60 -> 0.53 ms)
     __shared__ __attribute__((aligned(16))) float xs[TH * TW * PS];
-    __shared__ float ts[TH * TW * TS];
+    float* const ts = xs;
     SliceStage<CI, TH, TW, NT> stg;
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tw = bid % ntw; bid /= ntw;
@@ -250,6 +252,7 @@ __global__ __launch_bounds__(256) void deconv5_tail_mfma_kernel(const float* __r
 #pragma unroll
                 for (int q = 0; q < 4; ++q) b[i][q] = *reinterpret_cast<const f32x4*>(src + 4 * q);
             }
+            __syncthreads();                            // every wave holds its fragments: xs may be overwritten with partials
             f32x16 acc[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
