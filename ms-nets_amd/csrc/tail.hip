@@ -9,6 +9,9 @@
 //   msnet_deconv3d_cout1      : gcnet_3dcnn.py:88-92 un-fused (stride 2, or stride 4 / output_padding 3)
 #include "common.h"
 
+#ifndef TAIL_MINB
+#define TAIL_MINB 1
+#endif
 #ifndef TAIL_RT
 #define TAIL_RT 8
 #endif
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(RT * 32) void deconv5_tail_kernel(const float* __re
 // A workgroup owns 8 x 32 input voxels per slice (8 M-blocks, two per wave) and finishes the 7 x 31 columns whose
 // neighbours (h+1, w+1) are inside it; tiles overlap by one row / column (18 % extra MFMA work, no halo exchange).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void deconv5_tail_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 float bias, float* __restrict__ out, int N, int D, int H,
                                                                 int W, int nth, int ntw) {
     constexpr int CI = 32, TH = 8, TW = 32, UH = 7, UW = 31, PS = CI + 4, TS = 33, NT = 256;

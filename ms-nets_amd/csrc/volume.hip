@@ -167,8 +167,21 @@ __global__ void sadsob_vertical_kernel(const float* __restrict__ sl, const float
         for (int i = 1; i <= H; ++i) col[(size_t)i * (W + 1)] = 0.f;
         return;
     }
+    // the running sum is a strictly sequential float32 chain (the reference's order); only the loads are batched so
+    // that their latency is paid once per 8 rows instead of once per row
     float run = 0.f;
-    for (int i = 1; i <= H; ++i) {
+    int i = 1;
+    for (; i + 7 <= H; i += 8) {
+        float a[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a[k] = fabsf(sl[(i - 1 + k) * W + j] - sr[(i - 1 + k) * W + j - d]);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            run = a[k] + run;
+            col[(size_t)(i + k) * (W + 1)] = run;
+        }
+    }
+    for (; i <= H; ++i) {
         const float a = fabsf(sl[(i - 1) * W + j] - sr[(i - 1) * W + j - d]);
         run = a + run;
         col[(size_t)i * (W + 1)] = run;
@@ -186,15 +199,35 @@ __global__ __launch_bounds__(64) void sadsob_horizontal_kernel(float* __restrict
     float run = 0.f;                            // slice[row][d] == 0
     for (int c0 = d + 1; c0 <= W; c0 += 64) {
         const int ncols = min(64, W + 1 - c0);
-        for (int rr = 0; rr < nrows; ++rr)
-            if (lane < ncols) tile[rr][lane] = base[(size_t)(row0 + rr) * (W + 1) + c0 + lane];
+        if (nrows == 64 && ncols == 64) {       // full tile: all 64 row loads in flight before the first LDS write
+            float t[64];
+#pragma unroll
+            for (int rr = 0; rr < 64; ++rr) t[rr] = base[(size_t)(row0 + rr) * (W + 1) + c0 + lane];
+#pragma unroll
+            for (int rr = 0; rr < 64; ++rr) tile[rr][lane] = t[rr];
+        } else {
+            for (int rr = 0; rr < nrows; ++rr)
+                if (lane < ncols) tile[rr][lane] = base[(size_t)(row0 + rr) * (W + 1) + c0 + lane];
+        }
         __syncthreads();
-        if (lane < nrows)
-            for (int k = 0; k < ncols; ++k) {
-                run = tile[lane][k] + run;
-                tile[lane][k] = run;
+        if (lane < nrows) {
+            if (ncols == 64) {                  // row segment through registers: the add chain no longer waits on LDS per step
+                float v[64];
+#pragma unroll
+                for (int k = 0; k < 64; ++k) v[k] = tile[lane][k];
+#pragma unroll
+                for (int k = 0; k < 64; ++k) { run = v[k] + run; v[k] = run; }
+#pragma unroll
+                for (int k = 0; k < 64; ++k) tile[lane][k] = v[k];
+            } else {
+                for (int k = 0; k < ncols; ++k) {
+                    run = tile[lane][k] + run;
+                    tile[lane][k] = run;
+                }
             }
+        }
         __syncthreads();
+#pragma unroll 8
         for (int rr = 0; rr < nrows; ++rr)
             if (lane < ncols) base[(size_t)(row0 + rr) * (W + 1) + c0 + lane] = tile[rr][lane];
         __syncthreads();
@@ -356,9 +389,7 @@ struct FusedArgs {
 };
 
 // per-pixel tables: NCC (A, C) of both images and ZSAD means of both images, at window-centre coordinates
-__global__ void pixel_tables_kernel(FusedArgs a) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
-    if (x >= a.Wb) return;
+__device__ __forceinline__ void pixel_tables_px(const FusedArgs& a, int x, int y) {
     const int W = a.Wb, H = a.Hb;
     const size_t c = (size_t)y * W + x;
     {   // NCC
@@ -638,6 +669,49 @@ __global__ void preprocess_kernel(PrepArgs a) {
     a.out[(size_t)yo * Wb + xo] = v;
 }
 
+// The five independent per-pixel preparations in one launch (blockIdx.z): census bits L / R, NCC + ZSAD tables, Sobel L / R.
+__device__ __forceinline__ void census_transform_px(const uint8_t* __restrict__ img, uint32_t* __restrict__ bits, int H, int W,
+                                                    int ws, int nwords, int x, int y) {
+    const int wc = ws / 2;
+    const int i = y - wc, j = x - wc;
+    uint32_t wd[kCensusWords];
+#pragma unroll
+    for (int k = 0; k < kCensusWords; ++k) wd[k] = 0;
+    if (i >= 0 && j >= 0 && i < H - ws && j < W - ws) {
+        const int c = img[y * W + x];
+        int b = 0;
+        for (int wh = 0; wh < ws; ++wh)
+            for (int ww = 0; ww < ws; ++ww, ++b)
+                if (c < (int)img[(i + wh) * W + j + ww]) {
+#pragma unroll
+                    for (int k = 0; k < kCensusWords; ++k)
+                        if (k == (b >> 5)) wd[k] |= 1u << (b & 31);
+                }
+    }
+    for (int k = 0; k < nwords; ++k) bits[((size_t)y * W + x) * nwords + k] = wd[k];
+}
+__device__ __forceinline__ void sobel_px(const uint8_t* __restrict__ img, float* __restrict__ out, int H, int W, int x, int y) {
+    const int i = y - 1, j = x - 1;
+    float v = 0.f;
+    if (i >= 0 && j >= 0 && i < H - 3 && j < W - 3) {
+        const uint8_t* p = img + i * W + j;
+        const int sv = -(int)p[0] + (int)p[2] - 2 * (int)p[W] + 2 * (int)p[W + 2] - (int)p[2 * W] + (int)p[2 * W + 2];
+        v = (float)sv;
+    }
+    out[y * W + x] = v;
+}
+__global__ __launch_bounds__(64) void volume_prep_kernel(FusedArgs a, float* __restrict__ sobl, float* __restrict__ sobr) {
+    const int x = blockIdx.x * 64 + threadIdx.x, y = blockIdx.y;
+    if (x >= a.Wb) return;
+    switch (blockIdx.z) {
+    case 0: census_transform_px(a.l, const_cast<uint32_t*>(a.lb), a.Hb, a.Wb, a.censw, a.nwords, x, y); break;
+    case 1: census_transform_px(a.r, const_cast<uint32_t*>(a.rb), a.Hb, a.Wb, a.censw, a.nwords, x, y); break;
+    case 2: pixel_tables_px(a, x, y); break;
+    case 3: sobel_px(a.l, sobl, a.Hb, a.Wb, x, y); break;
+    default: sobel_px(a.r, sobr, a.Hb, a.Wb, x, y); break;
+    }
+}
+
 static inline int grid1d(size_t total, int cap = 16384) {
     const size_t b = (total + 255) / 256;
     return (int)(b < (size_t)cap ? (b ? b : 1) : cap);
@@ -830,14 +904,9 @@ extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, in
     a.Hb = Hb; a.Wb = Wb; a.nd = ndisp; a.bh = p.border_h; a.bw = p.border_w; a.Hc = Hc; a.Wc = Wc;
     a.censw = p.censw; a.nccw = p.nccw; a.sadw = p.sadw; a.sobelw = p.sobelw; a.nwords = nwords;
 
-    dim3 g2(cdiv(Wb, 64), Hb);
     {
         LaunchScope ls("volume_prep", s, 0, 2.0 * img * (1 + 4.0 * nwords) + 48.0 * img);
-        hipLaunchKernelGGL(census_transform_kernel, g2, dim3(64), 0, s, l, const_cast<uint32_t*>(a.lb), Hb, Wb, p.censw, nwords);
-        hipLaunchKernelGGL(census_transform_kernel, g2, dim3(64), 0, s, r, const_cast<uint32_t*>(a.rb), Hb, Wb, p.censw, nwords);
-        hipLaunchKernelGGL(pixel_tables_kernel, g2, dim3(64), 0, s, a);
-        hipLaunchKernelGGL(sobel_kernel, g2, dim3(64), 0, s, l, sobl, Hb, Wb);
-        hipLaunchKernelGGL(sobel_kernel, g2, dim3(64), 0, s, r, sobr, Hb, Wb);
+        hipLaunchKernelGGL(volume_prep_kernel, dim3(cdiv(Wb, 64), Hb, 5), dim3(64), 0, s, a, sobl, sobr);
     }
     {
         LaunchScope ls("sadsob_vertical", s, 0, 4.0 * ndisp * (double)(Hb + 1) * (Wb + 1));
