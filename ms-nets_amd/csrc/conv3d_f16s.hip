@@ -1293,7 +1293,7 @@ static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
 
 // Sliding-window launch for single-chunk stride-1 layers.  A tile column (all d at one (h, w) tile) is cut into `nseg`
 // segments that are dealt to the persistent workgroups; within a segment every tile after the first stages two planes
-// instead of four (modelled as 0.8 of a tile), so longer segments are cheaper per tile but balance worse.  Returns -1
+// instead of four (measured: 0.9 of a tile's time), so longer segments are cheaper per tile but balance worse.  Returns -1
 // when plain tiles are estimated to be no slower (the caller then launches the ordinary kernel).
 template <int TH, int TW, int MB, int NB>
 static int launch_f16s_slide(const char* name, ConvArgs a, hipStream_t s) {
@@ -1309,7 +1309,7 @@ static int launch_f16s_slide(const char* name, ConvArgs a, hipStream_t s) {
         if (a.ntd % seg) continue;
         const int len = a.ntd / seg;
         if (len < 2) break;
-        const double cost = ceil((double)cols * seg / G) * (1.0 + 0.8 * (len - 1));
+        const double cost = ceil((double)cols * seg / G) * (1.0 + 0.9 * (len - 1));
         if (cost < 0.97 * best) { best = cost; best_seg = seg; }
     }
     if (const char* e = getenv("MSNET_FORCE_SLIDE_SEG")) {     // test hook: force the sliding kernel with this many segments
