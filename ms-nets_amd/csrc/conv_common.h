@@ -158,70 +158,11 @@ __device__ __forceinline__ void epilogue_store(const f32x16& acc, const f32x16& 
     }
 }
 
-// ---- voxel-lane epilogue (split-fp16 kernels) ------------------------------------------------------------------------
-// Those kernels feed the MFMA with the weights as operand A and the voxels as operand B, so in the 32x32 result a LANE is
-// a voxel (l & 31) and register e is output channel 8*(e>>2) + 4*(l>>5) + (e&3) of the 32-channel block: four runs of
-// four consecutive channels per lane.  The epilogue then moves 16 bytes per lane and instruction (4 buffer ops per
-// block instead of 16 dword ops; a dword store instruction costs the CU's store path the same ~16 cycles as a 16-byte
-// one) and needs no per-element bounds logic: `voff` is the byte offset of (voxel, first channel of the block) +
-// 16*(l>>5) inside the sample, or 0xffffffff for a voxel outside the tensor -> loads return 0, stores are dropped.
-typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void residual_load_vox(f32x16& rv, __amdgpu_buffer_rsrc_t res, unsigned voff) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const unsigned o = voff == 0xffffffffu ? voff : voff + 32u * g;
-        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(res, o, 0, 0));
-        rv[4 * g] = t[0]; rv[4 * g + 1] = t[1]; rv[4 * g + 2] = t[2]; rv[4 * g + 3] = t[3];
-    }
-}
-
-// sc / sh: per-channel scale and shift of this block, already advanced by 4*(l>>5) floats; either may be null.
-__device__ __forceinline__ void epilogue_vox(const f32x16& acc, const f32x16& rv, const float* __restrict__ sc,
-                                             const float* __restrict__ sh, __amdgpu_buffer_rsrc_t y, unsigned voff,
-                                             int relu) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        if (sc) v = v * *reinterpret_cast<const f32x4*>(sc + 8 * g);
-        if (sh) v = v + *reinterpret_cast<const f32x4*>(sh + 8 * g);
-        v = v + f32x4{rv[4 * g], rv[4 * g + 1], rv[4 * g + 2], rv[4 * g + 3]};
-        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        const unsigned o = voff == 0xffffffffu ? voff : voff + 32u * g;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), y, o, 0, 0);
-    }
-}
-
-// The same epilogue split into "finish the values" and "store one 16-byte piece" for kernels that drain a finished block
-// through the CU's store path (about 16 B/clk) while the next block's MFMAs run, instead of stalling on a burst.
-__device__ __forceinline__ void finalize_vox(f32x16& out, const f32x16& acc, const f32x16& rv, const float* __restrict__ sc,
-                                             const float* __restrict__ sh, int relu) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        f32x4 v = {acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]};
-        if (sc) v = v * *reinterpret_cast<const f32x4*>(sc + 8 * g);
-        if (sh) v = v + *reinterpret_cast<const f32x4*>(sh + 8 * g);
-        v = v + f32x4{rv[4 * g], rv[4 * g + 1], rv[4 * g + 2], rv[4 * g + 3]};
-        if (relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-        out[4 * g] = v[0]; out[4 * g + 1] = v[1]; out[4 * g + 2] = v[2]; out[4 * g + 3] = v[3];
-    }
-}
-
-template <int G>
-__device__ __forceinline__ void store_piece_vox(const f32x16& v, __amdgpu_buffer_rsrc_t y, unsigned voff) {
-    const f32x4 t = {v[4 * G], v[4 * G + 1], v[4 * G + 2], v[4 * G + 3]};
-    const unsigned o = voff == 0xffffffffu ? voff : voff + 32u * G;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, t), y, o, 0, 0);
-}
-
-// accumulator start values of the voxel-lane layout: the block's per-channel shift (or zero)
-__device__ __forceinline__ void shift_init_vox(f32x16& v, const float* __restrict__ sh) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const f32x4 t = sh ? *reinterpret_cast<const f32x4*>(sh + 8 * g) : f32x4{0.f, 0.f, 0.f, 0.f};
-        v[4 * g] = t[0]; v[4 * g + 1] = t[1]; v[4 * g + 2] = t[2]; v[4 * g + 3] = t[3];
-    }
-}
+// (A voxel-lane variant of this epilogue -- weights as MFMA operand A, so that a lane holds four consecutive channels of
+// one voxel and moves 16 bytes per buffer op -- was built and measured: 4x fewer instructions but every instruction then
+// touches 32 cache lines instead of 2, and a CU's store path drains ~16 B/clk either way; +-1 %, dropped.  Draining a
+// finished block one piece per K-step under the next block's MFMAs did not help either: the bursts that cost time are the
+// residual loads and the tile hand-over)
 
 // LDS-only workgroup barrier: orders LDS traffic across the s_barrier without draining the vector-memory
 // counter (a plain __syncthreads() may add s_waitcnt vmcnt(0), which would stall the compute waves on their
