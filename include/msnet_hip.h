@@ -62,6 +62,9 @@ size_t msnet_sadsob_workspace_bytes(int H, int W, int ndisp);
 /* ---- featextract: replaces src/cpp/featextract/featextract.cpp:529-553 (libfeatextract) ----- */
 /* swap_axes(cost) featextract.cpp:49-76.  in: f32[D][H][W] -> out: f32[H][W][D]. */
 int msnet_swap_axes(const float* in, float* out, int D, int H, int W, msnet_stream_t stream);
+/* featextract.cpp:136-172 get_right_cost (only reached by extract_features_lr, cbmv_generator.py:84-254, i.e. with
+ * is_left_only=False): out[i][j][d] = cost[i][j+d][d] for j < W-d, else cost[0][0][0].  cost, out: f32[H][W][D], distinct. */
+int msnet_get_right_cost(const float* cost, float* out, int H, int W, int D, msnet_stream_t stream);
 /* extract_likelihood(vol,sigma) = extract_aml_testing, featextract.cpp:415-462.  vol,out: f32[P][D]. */
 int msnet_extract_likelihood(const float* vol, float* out, long P, int D, float sigma,
                              msnet_stream_t stream);

@@ -32,6 +32,7 @@ SIGNATURES = {
     "msnet_sadsob": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "msnet_sadsob_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "msnet_swap_axes": (c_int, [P, P, c_int, c_int, c_int, P]),
+    "msnet_get_right_cost": (c_int, [P, P, c_int, c_int, c_int, P]),
     "msnet_extract_likelihood": (c_int, [P, P, c_long, c_int, c_float, P]),
     "msnet_extract_features_left": (c_int, [P, P, P, P, P, c_long, c_int, c_float, c_float, c_float, P]),
     "msnet_volume_default_params": (None, [ctypes.POINTER(VolumeParams)]),

@@ -57,6 +57,21 @@ def extract_features_left(census, ncc, sobel, sad, cens_sigma=128.0, ncc_sigma=0
     return out.cpu().numpy() if was_numpy else out
 
 
+def extract_features_lr(census, ncc, sobel, sad, cens_sigma=128.0, ncc_sigma=0.02, sad_sigma=20000.0, sobel_sigma=20000.0,
+                        disp_image=None):
+    """cbmv_generator.py:84-254 (the is_left_only=False branch of generate_test_cbmv): -> [16, ndisp, H', W'] float32,
+    channels 0-7 as extract_features_left, 8-15 the same eight features of the right costs (get_right_cost of each
+    cropped left cost).  Four re-indexing launches + two feature launches; costs stay on the device."""
+    was_numpy = isinstance(census, np.ndarray)
+    if was_numpy:
+        census, ncc, sobel, sad = (torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (census, ncc, sobel, sad))
+    left = extract_features_left(census, ncc, sobel, sad, cens_sigma, ncc_sigma, sad_sigma, sobel_sigma)
+    right = extract_features_left(*(fte.get_right_cost(c) for c in (census, ncc, sobel, sad)),
+                                  cens_sigma, ncc_sigma, sad_sigma, sobel_sigma)
+    out = torch.cat([left, right], dim=0)
+    return out.cpu().numpy() if was_numpy else out
+
+
 class VolumeBuilder:
     """Fused build: owns the workspace for one (Hb, Wb, ndisp) shape so repeated calls allocate nothing."""
 

@@ -712,6 +712,18 @@ __global__ __launch_bounds__(64) void volume_prep_kernel(FusedArgs a, float* __r
     }
 }
 
+// featextract.cpp:136-172 get_right_cost: res[i][j][d] = cost[i][j+d][d] for j < W-d, else cost[0][0][0] (the fill value the
+// reference takes from the first element); cost / res are [H][W][D] float32.
+__global__ void right_cost_kernel(const float* __restrict__ cost, float* __restrict__ res, int H, int W, int D) {
+    const size_t total = (size_t)H * W * D;
+    const float fill = cost[0];
+    for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
+        const int d = (int)(o % D);
+        const int j = (int)((o / D) % W);
+        res[o] = (j < W - d) ? cost[o + (size_t)d * D] : fill;
+    }
+}
+
 static inline int grid1d(size_t total, int cap = 16384) {
     const size_t b = (total + 255) / 256;
     return (int)(b < (size_t)cap ? (b ? b : 1) : cap);
@@ -823,6 +835,17 @@ extern "C" int msnet_swap_axes(const float* in, float* out, int D, int H, int W,
     LaunchScope ls("swap_axes", s, 0, 8.0 * D * (double)S);
     hipLaunchKernelGGL(swap_axes_kernel, dim3((unsigned)((S + 63) / 64), cdiv(D, 64)), dim3(256), 0, s, in, out, D, S);
     return check_launch("msnet_swap_axes");
+}
+
+extern "C" int msnet_get_right_cost(const float* cost, float* out, int H, int W, int D, msnet_stream_t stream) {
+    if (!cost || !out) return fail("msnet_get_right_cost: null pointer");
+    if (cost == out) return fail("msnet_get_right_cost: in-place is not supported");
+    if (D <= 0 || H <= 0 || W <= 0) return fail("msnet_get_right_cost: empty tensor");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t total = (size_t)H * W * D;
+    LaunchScope ls("get_right_cost", s, 0, 8.0 * total);
+    hipLaunchKernelGGL(right_cost_kernel, dim3(grid1d(total)), dim3(256), 0, s, cost, out, H, W, D);
+    return check_launch("msnet_get_right_cost");
 }
 
 extern "C" int msnet_extract_likelihood(const float* vol, float* out, long P, int D, float sigma, msnet_stream_t stream) {

@@ -18,6 +18,18 @@ def swap_axes(cost):
     return _ret(out, npy)
 
 
+def get_right_cost(cost):
+    """float32 [H, W, D] left cost -> right cost (featextract.cpp:136-172): res[i,j,d] = cost[i,j+d,d] where j+d < W, else the
+    fill value cost[0,0,0]."""
+    t, npy = _to_dev(cost, _F32, "cost")
+    if t.dim() != 3:
+        raise ValueError("cost must be [H,W,D]")
+    H, W, D = t.shape
+    out = torch.empty_like(t)
+    check(_lib.load().msnet_get_right_cost(ptr(t), ptr(out), H, W, D, stream_ptr()), "msnet_get_right_cost")
+    return _ret(out, npy)
+
+
 def extract_likelihood(vol, sigma):
     """float32 [P, D] -> [P, D] per-row likelihood exp(-(c-min)^2/sigma) / sum (the 2-argument overload,
     featextract.cpp:546-549)."""

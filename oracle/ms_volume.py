@@ -142,6 +142,25 @@ def extract_features_left(census_c, ncc_c, sobel_c, sad_c, cens_sigma=128.0, ncc
     return feats.transpose((0, 3, 1, 2)).astype(np.float32)
 
 
+def get_right_cost(cost):
+    """featextract.cpp:136-172: res[i,j,d] = cost[i,j+d,d] for j < W-d, everything else = cost[0,0,0]."""
+    cost = np.ascontiguousarray(cost, np.float32)
+    h, w, nd = cost.shape
+    res = np.full_like(cost, cost[0, 0, 0])
+    for d in range(nd):
+        res[:, : w - d, d] = cost[:, d:, d]
+    return res
+
+
+def extract_features_lr(census_c, ncc_c, sobel_c, sad_c, cens_sigma=128.0, ncc_sigma=0.02, sad_sigma=20000.0,
+                        sobel_sigma=20000.0):
+    """cbmv_generator.py:84-254: channels 0-7 = the left features, 8-15 = the same features of get_right_cost(cost)."""
+    left = extract_features_left(census_c, ncc_c, sobel_c, sad_c, cens_sigma, ncc_sigma, sad_sigma, sobel_sigma)
+    right = extract_features_left(get_right_cost(census_c), get_right_cost(ncc_c), get_right_cost(sobel_c),
+                                  get_right_cost(sad_c), cens_sigma, ncc_sigma, sad_sigma, sobel_sigma)
+    return np.concatenate([left, right], axis=0)
+
+
 def build_ms_volume(imgl_board, imgr_board, ndisp, board=10):
     """The test-time call sequence of generate_test_cbmv (cbmv_generator.py:826-839) on already
     down-sampled, bordered uint8 images: get_costs(..., 11,3,5,5, 10,10,10) -> extract_features_left."""

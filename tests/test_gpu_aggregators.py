@@ -380,6 +380,21 @@ def test_full_benchmark_shape_matches_oracle(gpu, model_name, in_shape, maxdisp)
         assert ours <= noise + DISP_TOL
 
 
+def test_gcnet_16_plane_volume(gpu):
+    """cbmv_in_planes=16 (the left+right volume of SURVEY 8(f).2): the first layer then has 16 input channels, which has
+    no split-fp16 kernel and runs on the fp32 MFMA; everything else as usual.  Checked against the oracle."""
+    from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre
+    torch.manual_seed(3)
+    model = GCNet_CostVolumeAggre(maxdisp=32, cbmv_in_planes=16).eval()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.rand((1, 16, 16, 16, 48), generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        ref = oracle.gcnet_forward(sd, x, 32)
+    got = model.cuda()(x.cuda()).cpu()
+    assert tuple(got.shape) == tuple(ref.shape) == (1, 32, 96)
+    assert float((got - ref).abs().max()) <= DISP_TOL
+
+
 def test_psmnet_all_heads(gpu):
     case = recipes.AGG_CASES["psmnet_small"]
     model = recipes.build_case(case, *_our_classes())

@@ -124,6 +124,23 @@ def test_unfused_pipeline_matches_fused(gpu):
     assert np.abs(feats[4:] - fused[4:]).max() <= 2e-6
 
 
+def test_left_right_features(gpu):
+    """get_right_cost + extract_features_lr (the 16-channel volume of is_left_only=False)."""
+    from msnets_amd import cbmv_generator as cg, libfeatextract as fte
+    l, r = _pair(60, 90, 12, 9, "texture")
+    costs = O.get_costs(l, r, 12, 11, 3, 5, 5, 10, 10, 10)
+    for c, nm in zip(costs, ["census", "ncc", "sobel", "sad"]):
+        _bitexact(fte.get_right_cost(c), O.get_right_cost(c), "get_right_cost " + nm)
+    ref = O.extract_features_lr(*costs)
+    got = cg.extract_features_lr(*costs)
+    assert got.shape == ref.shape == (16, 12, 40, 70)
+    for ch in (0, 1, 2, 3, 8, 9, 10, 11):
+        _bitexact(got[ch], ref[ch], "cost channel %d" % ch)
+    assert np.abs(got - ref).max() <= 2e-6
+    with pytest.raises(ValueError):
+        fte.get_right_cost(costs[0][0])
+
+
 def test_planted_disparity_recovered(gpu):
     """Size-independent property at a benchmark shape: census argmin recovers the planted shift."""
     from msnets_amd import cbmv_generator as cg, synthetic

@@ -139,3 +139,14 @@ def test_sentinels_become_one_in_costs_and_zero_in_aml():
     # cropped column x has census costs only for d <= x + 5
     assert np.all(vol[0, 10:, :, 0] == 1.0) and np.all(vol[4, 10:, :, 0] == 0.0)
     assert np.all(vol[3, 12:, :, 2] == 1.0)          # zsad: d <= x + 8
+
+
+def test_get_right_cost_known_answer():
+    """featextract.cpp:136-172: res[i,j,d] = cost[i,j+d,d], the uncovered right margin takes cost[0,0,0]."""
+    from oracle import ms_volume as O
+    cost = np.arange(2 * 5 * 3, dtype=np.float32).reshape(2, 5, 3) + 100
+    res = O.get_right_cost(cost)
+    assert res[1, 2, 0] == cost[1, 2, 0] and res[1, 2, 1] == cost[1, 3, 1] and res[0, 2, 2] == cost[0, 4, 2]
+    assert res[1, 4, 1] == cost[0, 0, 0] and res[0, 3, 2] == cost[0, 0, 0]
+    feats = O.extract_features_lr(cost, cost / 200 - 1, cost, cost)
+    assert feats.shape == (16, 3, 2, 5) and feats.dtype == np.float32
