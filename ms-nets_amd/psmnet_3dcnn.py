@@ -46,10 +46,14 @@ def _classif():
 
 
 class PSMNet_CostVolumeAggre(nn.Module):
-    def __init__(self, maxdisp):
+    def __init__(self, maxdisp, in_planes=64):
+        """in_planes: channels of the input volume.  64 is the reference (a PSMNet feature-concat volume,
+        psmnet_3dcnn.py:97); 8 (or 16) lets the aggregator take the matching-space volume directly, which the reference's
+        class cannot (SURVEY defect D3) -- an extension, not part of the parity contract."""
         super().__init__()
         self.maxdisp = maxdisp
-        self.dres0 = nn.Sequential(_convbn(64, 32, 1), nn.ReLU(inplace=True), _convbn(32, 32, 1), nn.ReLU(inplace=True))
+        self.in_planes = int(in_planes)
+        self.dres0 = nn.Sequential(_convbn(self.in_planes, 32, 1), nn.ReLU(inplace=True), _convbn(32, 32, 1), nn.ReLU(inplace=True))
         self.dres1 = nn.Sequential(_convbn(32, 32, 1), nn.ReLU(inplace=True), _convbn(32, 32, 1))
         self.dres2 = hourglass(32)
         self.dres3 = hourglass(32)
@@ -127,8 +131,8 @@ class PSMNet_CostVolumeAggre(nn.Module):
         if self.training:
             raise RuntimeError("PSMNet_CostVolumeAggre (HIP) is forward/inference only: call .eval() first")
         cost = hipops.require_gpu_f32(cost, "cost")
-        if cost.dim() != 5 or cost.shape[1] != 64:
-            raise ValueError("cost must be [N,64,D/4,H/4,W/4] (got %s)" % (tuple(cost.shape),))
+        if cost.dim() != 5 or cost.shape[1] != self.in_planes:
+            raise ValueError("cost must be [N,%d,D/4,H/4,W/4] (got %s)" % (self.in_planes, tuple(cost.shape)))
         return cost
 
     def forward(self, cost, out_hw=None, taps=None):

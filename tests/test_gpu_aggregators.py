@@ -395,6 +395,23 @@ def test_gcnet_16_plane_volume(gpu):
     assert float((got - ref).abs().max()) <= DISP_TOL
 
 
+def test_psmnet_takes_the_ms_volume(gpu):
+    """PSMNet-style aggregator with an 8-channel first layer (the MS volume); checked against the oracle,
+    whose dres0 follows the state_dict's shapes."""
+    from msnets_amd.psmnet_3dcnn import PSMNet_CostVolumeAggre
+    torch.manual_seed(5)
+    model = PSMNet_CostVolumeAggre(64, in_planes=8).eval()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = torch.rand((1, 8, 16, 12, 40), generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        ref = oracle.psmnet_forward(sd, x, 64, (48, 160))
+    got = model.cuda()(x.cuda()).cpu()
+    assert tuple(got.shape) == tuple(ref.shape) == (1, 48, 160)
+    assert float((got - ref).abs().max()) <= DISP_TOL
+    with pytest.raises(ValueError):
+        model(torch.rand((1, 64, 16, 12, 40)).cuda())
+
+
 def test_psmnet_all_heads(gpu):
     case = recipes.AGG_CASES["psmnet_small"]
     model = recipes.build_case(case, *_our_classes())
