@@ -650,6 +650,16 @@ __host__ __device__ constexpr DTap dtap(int k) {
     return DTap{0, 0, 0, 0, 0, 0, 1, 1, 1, 1};
 }
 
+// first group (in dtap order) of the class at position c of the class order
+__host__ __device__ constexpr int class_first_group(int c) {
+    int k = 0, pos = 0;
+    while (pos < c) {
+        if (dtap(k).last) ++pos;
+        ++k;
+    }
+    return k;
+}
+
 // dtap(k) as one word per group for the kernel's run-time loop: dd | dh<<1 | dw<<2 | pd<<3 | ph<<4 | pw<<5 | first<<6 | last<<7
 struct DeconvTapTable { int e[27]; };
 constexpr DeconvTapTable make_deconv_taps() {
@@ -686,6 +696,9 @@ __global__ void pack_deconv_weight_f16s_kernel(const float* __restrict__ w, _Flo
     }
 }
 
+#ifndef DEC_SPREAD_MIN
+#define DEC_SPREAD_MIN 2
+#endif
 #ifdef DEXP_NO_GBAR
 #define MSNET_DBAR() do {} while (0)
 #else
@@ -849,48 +862,71 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
         const int bh = mb % TH, bd = mb / TH;
         abase[i] = ((bd * IH + bh) * IW + r) * RB + 16 * hh;
     }
-    const int stride_w = 2 * a.Co * 4, stride_h = 2 * a.OW * a.Co * 4;  // bytes
+    const int stride_w = 2 * a.Co * 4;                  // bytes between the output voxels of consecutive input voxels
+
+    // The eight classes are expanded at compile time (their group loops stay rolled).  For the classes with two or more
+    // taps the residual is requested piece by piece during their first two groups -- four dword loads per K-step instead
+    // of a burst of 32 that blocks the wave for ~2300 cycles while the CU's memory pipe drains; the one-tap class keeps
+    // the burst (DEC_SPREAD_MIN = 2 / 4 / 8 measured: 1.08 / 1.10 / 1.12 ms on deconvbn4).  Requesting a whole class ahead was built too: it needs
+    // a second residual register set (spills) and, with 32 stores + 32 loads younger than the loads being waited for, runs
+    // into the 6-bit vmcnt, i.e. ends up waiting for store acknowledgements -- slower than this.
+    constexpr int PIECES = MB * NB * 16;
+    f32x16 acc0[MB][NB], acc1[MB][NB], rres[1][MB][NB];
+    unsigned obase[1][MB][NB];                          // byte offset of the lane's first output element
+    int wlim[1];                                        // a.W - iwb (column validity)
+    half8 ah[2][MB], al[2][MB], bh_[2][NB], bl[2][NB];
+    const size_t osample = (size_t)a.OD * a.OH * a.OW * a.Co * 4;
+
+    // output offsets of class (pd, ph, pw) of the tile at (d0, h0, w0), channel group nb0, into set `st`
+    auto set_bases = [&](int st, int d0, int h0, int w0, int nb0, int pd, int ph, int pw) {
+        wlim[st] = a.W - (w0 + 4 * hh);
+#pragma unroll
+        for (int i = 0; i < MB; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int mb = wm * MB + i;
+                const int ihb = h0 + mb % TH, iwb = w0 + 4 * hh, id = d0 + mb / TH;
+                obase[st][i][j] = (unsigned)(((((size_t)2 * id + pd) * a.OH + 2 * ihb + ph) * a.OW + 2 * iwb + pw) * a.Co +
+                                             (nb0 + j) * 32 + r) * 4u;
+                if (id >= a.D || ihb >= a.H) obase[st][i][j] = 0xffffffffu;     // whole M-block outside the input
+            }
+    };
+    // request pieces [q0, q0 + cnt) of set `st` (piece = (i, j, e); element e is voxel column (e&3) + 8*(e>>2))
+    auto request = [&](auto stc, auto q0c, auto cntc, __amdgpu_buffer_rsrc_t rs) {
+        constexpr int st = decltype(stc)::value, q0 = decltype(q0c)::value, cnt = decltype(cntc)::value;
+#pragma unroll
+        for (int q = q0; q < q0 + cnt; ++q) {
+            const int e = q % 16, j = (q / 16) % NB, i = q / (16 * NB);
+            const int c = (e & 3) + 8 * (e >> 2);
+            const unsigned ob = obase[st][i][j];
+            const unsigned o = (ob != 0xffffffffu && c < wlim[st]) ? ob + (unsigned)(c * stride_w) : 0xffffffffu;
+            rres[st][i][j][e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, o, 0, 0));
+        }
+    };
+    auto rs_res_of = [&](int n) { return make_rsrc(a.res ? a.res + (size_t)n * (osample / 4) : nullptr, a.res ? osample : 0); };
 
     for (int it = 0; it < nitems; ++it) {
         int n, d0, h0, w0, cg;
         decode(it, n, d0, h0, w0, cg);
         const int nb0 = cg * NB;
+        float sc[NB], sh[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            sc[j] = a.scale ? a.scale[(nb0 + j) * 32 + r] : 1.f;
+            sh[j] = a.shift ? a.shift[(nb0 + j) * 32 + r] : 0.f;
+        }
         MSNET_LDS_BARRIER();                            // b1
         MSNET_LDS_BARRIER();                            // b2
+#pragma unroll
+        for (int j = 0; j < NB; ++j) asm volatile("" : "+v"(sc[j]), "+v"(sh[j]));     // land them before the residual stream starts
         const int gg0 = it * 27;
-        f32x16 acc0[MB][NB], acc1[MB][NB], rres[MB][NB];
-        unsigned obase[MB][NB];                         // byte offset of the lane's first output element in sample n
-        half8 ah[2][MB], al[2][MB], bh_[2][NB], bl[2][NB];
-        const size_t osample = (size_t)a.OD * a.OH * a.OW * a.Co * 4;
         const auto rs_y = make_rsrc(a.y + (size_t)n * (osample / 4), osample);
-        const auto rs_res = make_rsrc(a.res ? a.res + (size_t)n * (osample / 4) : nullptr, a.res ? osample : 0);
-        // The 27 groups run as a real loop driven by a constant table: expanded at compile time the kernel was 88 KB of
-        // straight-line code, larger than the 64 KB instruction cache two CUs share, and ran at a quarter of the speed
-        // its MFMA / LDS / HBM budgets allow.  Everything indexed by k is wave-uniform (SGPRs); the accumulators and
-        // fragment registers keep static indices.
-        for (int k = 0; k < 27; ++k) {
+        const auto rs_res = rs_res_of(n);
+
+        // one weight group: KS K-steps of MB x NB x 3 MFMAs; `after(ks)` runs behind the MFMAs of step ks
+        auto group = [&](int k, int toff, auto after) {
             if (wave == 0) STAMP(0, sidx_d, lane);
-            const int te = __builtin_amdgcn_readfirstlane(kDeconvTaps.e[k]);
-            const int t_dd = te & 1, t_dh = (te >> 1) & 1, t_dw = (te >> 2) & 1;
-            const int t_pd = (te >> 3) & 1, t_ph = (te >> 4) & 1, t_pw = (te >> 5) & 1;
-            if (te & 64) {                              // first tap of a class: clear, and start its residual loads
-#pragma unroll
-                for (int i = 0; i < MB; ++i)
-#pragma unroll
-                    for (int j = 0; j < NB; ++j) {
-#pragma unroll
-                        for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
-                        const int mb = wm * MB + i;
-                        const int ihb = h0 + mb % TH, iwb = w0 + 4 * hh, id = d0 + mb / TH;
-                        obase[i][j] = (unsigned)(((((size_t)2 * id + t_pd) * a.OH + 2 * ihb + t_ph) * a.OW + 2 * iwb + t_pw) *
-                                                     a.Co + (nb0 + j) * 32 + r) * 4u;
-                        if (id >= a.D || ihb >= a.H) obase[i][j] = 0xffffffffu;     // whole M-block outside the input
-                        residual_prefetch<32>(rres[i][j], rs_res, obase[i][j], stride_h, stride_w,
-                                              [&](int, int lw) { return obase[i][j] != 0xffffffffu && iwb + lw < a.W; });
-                    }
-            }
             const unsigned char* bb = lds_b + ((gg0 + k) & 1) * GB + lane * 16;
-            const int toff = ((t_dd * IH + t_dh) * IW + t_dw) * RB;
             auto frag = [&](int ks, int slot) {
 #pragma unroll
                 for (int i = 0; i < MB; ++i) {
@@ -906,8 +942,8 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
                 }
             };
             frag(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
+            static_for<KS>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
                 if (ks + 1 < KS) frag(ks + 1, (ks + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -923,34 +959,59 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
                         acc1[i][j] = mfma16(ah[ks & 1][i], bl[ks & 1][j], acc1[i][j]);
 #endif
                     }
+                after(ksc);
                 __builtin_amdgcn_sched_barrier(0);
-            }
-            if (wave == 0) STAMP(0, sidx_d, lane);
+            });
             if (k < 26) MSNET_DBAR();                   // g_k: this group's weights are consumed, the next are published
+        };
+
+        static_for<8>([&](auto cc) {
+            constexpr int C = decltype(cc)::value;
+            constexpr int K0 = class_first_group(C);
+            constexpr DTap tc = dtap(K0);
+            constexpr int NT = (tc.pd + 1) * (tc.ph + 1) * (tc.pw + 1);        // groups (taps) of this class
+            constexpr bool SPREAD = NT >= DEC_SPREAD_MIN;                       // long classes: residual requested over two groups
+            constexpr int P = SPREAD ? 2 : 0;
+            constexpr int L = PIECES / (KS * 2);                                // requests per K-step when spread
+            static_assert(PIECES % (KS * 2) == 0, "request schedule");
+#pragma unroll
+            for (int i = 0; i < MB; ++i)
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
+            set_bases(0, d0, h0, w0, nb0, tc.pd, tc.ph, tc.pw);
+            if (!SPREAD)
+                request(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::integral_constant<int, PIECES>{}, rs_res);
+            static_for<P>([&](auto pc) {
+                constexpr int p = decltype(pc)::value;
+                constexpr DTap t = dtap(K0 + p);
+                group(K0 + p, ((t.dd * IH + t.dh) * IW + t.dw) * RB, [&](auto ksc) {
+                    constexpr int ks = decltype(ksc)::value;
+                    request(std::integral_constant<int, 0>{}, std::integral_constant<int, (p * KS + ks) * L>{},
+                            std::integral_constant<int, L>{}, rs_res);
+                });
+            });
+            for (int k = K0 + P; k < K0 + NT; ++k) {
+                const int te = __builtin_amdgcn_readfirstlane(kDeconvTaps.e[k]);
+                group(k, (((te & 1) * IH + ((te >> 1) & 1)) * IW + ((te >> 2) & 1)) * RB, [](auto) {});
+            }
+            // epilogue of class (pd, ph, pw): output voxels (2*id+pd, 2*ih+ph, 2*iw+pw)
             if (wave == 0) STAMP(0, sidx_d, lane);
 #ifdef DEXP_NO_EPI
-            if ((te & 128) && acc0[0][0][0] == 123.456f) {
-#else
-            if (te & 128) {
+            if (acc0[0][0][0] == 123.456f)
 #endif
-                // last tap of class (pd, ph, pw): epilogue to output voxels (2*id+pd, 2*ih+ph, 2*iw+pw)
 #pragma unroll
-                for (int i = 0; i < MB; ++i) {
-                    const int iwb = w0 + 4 * hh;
+            for (int i = 0; i < MB; ++i)
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) {
-                        const int co = (nb0 + j) * 32 + r;
-                        const float sc = a.scale ? a.scale[co] : 1.f;
-                        const float sh = a.shift ? a.shift[co] : 0.f;
-                        f32x16 v;
+                for (int j = 0; j < NB; ++j) {
+                    f32x16 v;
 #pragma unroll
-                        for (int e = 0; e < 16; ++e) v[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
-                        epilogue_store<32>(v, rres[i][j], sc, sh, rs_y, obase[i][j], stride_h, stride_w, a.relu,
-                                           [&](int, int lw) { return obase[i][j] != 0xffffffffu && iwb + lw < a.W; });
-                    }
+                    for (int e = 0; e < 16; ++e) v[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
+                    epilogue_store<32>(v, rres[0][i][j], sc[j], sh[j], rs_y, obase[0][i][j], 0, stride_w, a.relu,
+                                       [&](int, int lw) { return obase[0][i][j] != 0xffffffffu && lw < wlim[0]; });
                 }
-            }
-        }
+        });
     }
 }
 
