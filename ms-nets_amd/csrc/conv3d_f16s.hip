@@ -512,6 +512,59 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         }
     };
 
+    // DRAIN (sliding-window kernel, layers without a residual): the finished tile is not stored in a burst at the
+    // hand-over (32 KB per CU against a store path of ~16 B/clk: ~2000 cycles during which the MFMA waves do nothing
+    // else, and after the sliding window that burst IS the hand-over) but parked in `pend` and stored one element
+    // per K-step under the next tile's first groups.
+    constexpr bool DRAIN = SLIDE;
+    constexpr int PIECES = MB * NB * 16;
+    static_assert(!DRAIN || PIECES <= 9 * 3 * KS, "a tile's groups must cover the previous tile's pieces");
+    f32x16 pend[DRAIN ? MB : 1][DRAIN ? NB : 1];
+    unsigned pbase[MB][NB];
+    int plh[MB], plw[MB];
+    bool pend_live = false;
+    __amdgpu_buffer_rsrc_t pend_rs = make_rsrc(a.y, 0);
+    auto park = [&](int n, int od0, int oh0, int ow0, int cg) {
+        const size_t osample = (size_t)a.OD * a.OH * a.OW * a.Co * 4;
+        pend_rs = make_rsrc(a.y + (size_t)n * (osample / 4), osample);
+#pragma unroll
+        for (int i = 0; i < MB; ++i) {
+            const int mb = wm * MB + i;
+            const int bw_ = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
+            const int od = od0 + bd, ohb = oh0 + bh * BH, owb = ow0 + bw_ * BW + 4 * hh;
+            plh[i] = a.OH - ohb; plw[i] = a.OW - owb;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int co = (cg * NB + j) * 32 + r;
+                pbase[i][j] = od < a.OD ? (unsigned)((((size_t)od * a.OH + ohb) * a.OW + owb) * a.Co + co) * 4u : 0xffffffffu;
+                const float sc = a.scale ? a.scale[co] : 1.f;
+                const float sh = a.shift ? a.shift[co] : 0.f;
+                f32x16 t;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = (acc0[i][j][e] + acc1[i][j][e] * kLoInv) * sc + sh;
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    t[e] = v;
+                }
+                pend[DRAIN ? i : 0][DRAIN ? j : 0] = t;
+            }
+        }
+        pend_live = true;
+    };
+    auto drain_piece = [&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        if constexpr (DRAIN && q < PIECES) {
+            constexpr int e = q % 16, j = (q / 16) % NB, i = q / (16 * NB);
+            constexpr int c = (e & 3) + 8 * (e >> 2), lh = c / BW, lw = c % BW;
+            if (pend_live) {
+                const bool ok = pbase[i][j] != 0xffffffffu && lh < plh[i] && lw < plw[i];
+                const unsigned o = ok ? pbase[i][j] + (unsigned)(lh * stride_h + lw * stride_w) * 4u : 0xffffffffu;
+                const float val = pend[i][j][e];        // (bit_cast applied to the vector element itself reads element 0)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), pend_rs, o, 0, 0);
+            }
+        }
+    };
+
     int sidx = 0;
     for (int it = 0; it < nitems; ++it) {
         int n, od0, oh0, ow0, chunk, cg;
@@ -520,7 +573,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         if (wave == 0) STAMP(0, sidx, lane);
         MSNET_LDS_BARRIER();                            // b1
         if (wave == 0) STAMP(0, sidx, lane);
-        if (pending) { epilogue(pn, pod0, poh0, pow0, pcg); pending = false; }
+        if (pending) {
+            if (DRAIN && !a.res) park(pn, pod0, poh0, pow0, pcg);
+            else epilogue(pn, pod0, poh0, pow0, pcg);
+            pending = false;
+        }
         if (wave == 0) STAMP(0, sidx, lane);
         MSNET_LDS_BARRIER();                            // b2
         if (wave == 0) STAMP(0, sidx, lane);
@@ -575,15 +632,15 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         for (int i = 0; i < MB; ++i) goff_next[i] = grp_off(0, i);
 #pragma unroll
         for (int q = 0; q < PF; ++q) frag_a(q, q, goff_next);
-#pragma unroll 1
-        for (int g = 0; g < 9; ++g) {
+        // one weight group; `drain(s)` runs behind the MFMAs of step s (s as an integral_constant)
+        auto do_group = [&](int g, auto drain) {
             const unsigned char* bb = lds_b + (RESB ? g : ((gg0 + g) & 1)) * GB + lane * 16;
 #pragma unroll
             for (int i = 0; i < MB; ++i) { goff[i] = goff_next[i]; goff_next[i] = grp_off(g + 1, i); }   // (kd, kh) rows, in voxels
 #pragma unroll
             for (int q = 0; q < PF; ++q) frag_b(q, q, bb);
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
+            static_for<NS>([&](auto sc_) {
+                constexpr int s = decltype(sc_)::value;
 #ifndef EXP_NO_FRAG
                 if (s + PF < NS) { frag_a(s + PF, (s + PF) % R, goff); frag_b(s + PF, (s + PF) % R, bb); }
                 else if (g < 8) frag_a(s + PF - NS, (s + PF) % R, goff_next);
@@ -604,8 +661,9 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(bh_[s % R][j]), "v"(bl[s % R][j]));
 #endif
+                drain(sc_);
                 __builtin_amdgcn_sched_barrier(0);
-            }
+            });
 #ifndef EXP_NO_GROUP_BARRIER
             if (!RESB && g < 8) {
                 if (wave == 0) STAMP(0, sidx, lane);
@@ -613,6 +671,16 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
                 if (wave == 0) STAMP(0, sidx, lane);
             }
 #endif
+        };
+        if constexpr (DRAIN) {
+            static_for<9>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                do_group(g, [&](auto sc_) { drain_piece(std::integral_constant<int, g * NS + decltype(sc_)::value>{}); });
+            });
+            pend_live = false;
+        } else {
+#pragma unroll 1
+            for (int g = 0; g < 9; ++g) do_group(g, [](auto) {});
         }
         if (chunk == nchunks - 1) { pending = true; pn = n; pod0 = od0; poh0 = oh0; pow0 = ow0; pcg = cg; }
     }
