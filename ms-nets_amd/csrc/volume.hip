@@ -525,21 +525,49 @@ __device__ __forceinline__ void zsad_costs(const FusedArgs& a, int yb, int xb, F
 #pragma unroll
         for (int k = 0; k < NL; ++k) lm[k] = ok ? (float)a.l[(i + k / WD) * W + j + k % WD] - ml : 0.f;
     }
-    for (int d = 0; d < a.nd; ++d) {
-        float c = kSentinel;
-        if (ok && j >= d) {
-            const float mr = a.mr[cl - d];
-            const uint8_t* rp = a.r + i * W + j - d;
-            float acc = 0.f;
-            if (WS > 0) {
+    if constexpr (WS > 0) {
+        // WS disparities per round share one load of the 2*WS-1 right-image columns they touch (window of step u = columns
+        // WS-1-u .. 2*WS-2-u of the strip): 9 byte loads per disparity instead of 25 for the 5x5 window -- the pass was
+        // bound by the texture-address path, not the VALU.  Same (wh, ww) summation order as before.
+        constexpr int NC = 2 * WS - 1;
+        for (int d0 = 0; d0 < a.nd; d0 += WS) {
+            float rs[WS][NC];
+            const int c0 = j - d0 - (WS - 1);                       // image column of strip column 0
 #pragma unroll
-                for (int k = 0; k < NL; ++k) {
-                    float t = lm[k] - (float)rp[(k / WD) * W + k % WD];
-                    t = t + mr;
-                    acc = acc + fabsf(t);
+            for (int wh = 0; wh < WS; ++wh)
+#pragma unroll
+                for (int q = 0; q < NC; ++q) {
+                    const int col = c0 + q;
+                    rs[wh][q] = (ok && col >= 0) ? (float)a.r[(i + wh) * W + col] : 0.f;
                 }
-            } else {
+#pragma unroll
+            for (int u = 0; u < WS; ++u) {
+                const int d = d0 + u;
+                if (d < a.nd) {
+                    float c = kSentinel;
+                    if (ok && j >= d) {
+                        const float mr = a.mr[cl - d];
+                        float acc = 0.f;
+#pragma unroll
+                        for (int k = 0; k < NL; ++k) {
+                            float t = lm[k] - rs[k / WD][WS - 1 - u + k % WD];
+                            t = t + mr;
+                            acc = acc + fabsf(t);
+                        }
+                        c = acc;
+                    }
+                    emit(d, c);
+                }
+            }
+        }
+    } else {
+        for (int d = 0; d < a.nd; ++d) {
+            float c = kSentinel;
+            if (ok && j >= d) {
+                const float mr = a.mr[cl - d];
+                const uint8_t* rp = a.r + i * W + j - d;
                 const uint8_t* lp = a.l + i * W + j;
+                float acc = 0.f;
                 for (int wh = 0; wh < ws; ++wh)
                     for (int ww = 0; ww < ws; ++ww) {
                         float t = (float)lp[wh * W + ww] - ml;
@@ -547,10 +575,10 @@ __device__ __forceinline__ void zsad_costs(const FusedArgs& a, int yb, int xb, F
                         t = t + mr;
                         acc = acc + fabsf(t);
                     }
+                c = acc;
             }
-            c = acc;
+            emit(d, c);
         }
-        emit(d, c);
     }
 }
 
