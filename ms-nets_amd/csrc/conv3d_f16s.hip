@@ -1260,6 +1260,8 @@ static int launch_deconv_f16s(const char* name, ConvArgs a, hipStream_t s) {
     a.nbtot = a.Co / 32;
     const size_t nitems = (size_t)a.N * a.ntd * a.nth * a.ntw * a.ngroups;
     if (nitems == 0 || nitems > 0x7fffffffu) return fail("%s: bad item count %zu", name, nitems);
+    if ((size_t)a.OD * a.OH * a.OW * a.Co * 4 > 0xfffffff0u || (size_t)a.D * a.H * a.W * a.Ci * 4 > 0x7ffffff0u)
+        return fail("%s: a sample exceeds the buffer-descriptor range of this kernel (use the fp32 path)", name);
     const size_t nblk = nitems < (size_t)num_cus() ? nitems : (size_t)num_cus();
     const double ivox = (double)a.N * a.D * a.H * a.W;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * ivox, 4.0 * (ivox * a.Ci + 8.0 * ivox * a.Co * (a.res ? 2 : 1)));
@@ -1431,6 +1433,7 @@ static int launch_f16s_slide(const char* name, ConvArgs a, hipStream_t s) {
     a.ngroups = a.Co / (32 * NB); a.nbtot = a.Co / 32;
     const size_t cols = (size_t)a.N * a.nth * a.ntw * a.ngroups;
     if (cols == 0 || cols * a.ntd > 0x7fffffffu) return fail("%s: bad tile count", name);
+    if ((size_t)a.OD * a.OH * a.OW * a.Co * 4 > 0xfffffff0u) return -1;    // drained stores use 32-bit offsets inside a sample
     const double G = (double)num_cus();
     double best = ceil((double)cols * a.ntd / G);       // plain tiles, one unit of time each
     int best_seg = 0;
