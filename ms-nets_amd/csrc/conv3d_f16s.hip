@@ -1414,6 +1414,8 @@ static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     a.ngroups = a.Co / (32 * NB); a.nbtot = a.Co / 32;
     const size_t ntiles = (size_t)a.N * a.ntd * a.nth * a.ntw * a.ngroups;
     if (ntiles == 0 || ntiles > 0x7fffffffu) return fail("%s: bad tile count %zu", name, ntiles);
+    if ((size_t)a.D * a.H * a.W * a.Ci * 4 > 0x7ffffff0u)
+        return fail("%s: an input sample exceeds 2 GB, the range of the loaders' buffer descriptor (use the fp32 path)", name);
     const size_t nblk = ntiles < (size_t)num_cus() ? ntiles : (size_t)num_cus();
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
@@ -1433,7 +1435,8 @@ static int launch_f16s_slide(const char* name, ConvArgs a, hipStream_t s) {
     a.ngroups = a.Co / (32 * NB); a.nbtot = a.Co / 32;
     const size_t cols = (size_t)a.N * a.nth * a.ntw * a.ngroups;
     if (cols == 0 || cols * a.ntd > 0x7fffffffu) return fail("%s: bad tile count", name);
-    if ((size_t)a.OD * a.OH * a.OW * a.Co * 4 > 0xfffffff0u) return -1;    // drained stores use 32-bit offsets inside a sample
+    if ((size_t)a.OD * a.OH * a.OW * a.Co * 4 > 0xfffffff0u || (size_t)a.D * a.H * a.W * a.Ci * 4 > 0x7ffffff0u)
+        return -1;                                      // 32-bit offsets inside a sample (drained stores, loader descriptor)
     const double G = (double)num_cus();
     double best = ceil((double)cols * a.ntd / G);       // plain tiles, one unit of time each
     int best_seg = 0;
