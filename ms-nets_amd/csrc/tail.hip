@@ -372,6 +372,87 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict
     }
 }
 
+// The same head with the channel contraction on the fp32 MFMA (see deconv5_tail_mfma_kernel): per input slice every voxel's
+// 27 tap partials T[voxel][tap] are computed once, parked in LDS, and each output voxel (h, w) adds, for kd = 0,1,2, the nine
+// partials T[(h+kh-1, w+kw-1)][kd,kh,kw] of its 3x3 neighbourhood; kd = 2 finishes out[P-1], kd = 1 goes to out[P], kd = 0 to
+// out[P+1].  A workgroup multiplies 8 x 32 input voxels per slice (origin h0-1, w0-1) and finishes the inner 6 x 30 outputs.
+__global__ __launch_bounds__(256) void conv_cout1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ add, float* __restrict__ y, int N,
+                                                              int D, int H, int W, int nth, int ntw) {
+    constexpr int CI = 32, TH = 8, TW = 32, UH = 6, UW = 30, PS = CI + 4, TS = 33, NT = 256;
+    __shared__ __attribute__((aligned(16))) float xs[TH * TW * PS];
+    float* const ts = xs;                               // partials reuse the slice buffer (TS <= PS)
+    SliceStage<CI, TH, TW, NT> stg;
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tw = bid % ntw; bid /= ntw;
+    const int th = bid % nth;
+    const int n = bid / nth;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, kq = lane >> 5;
+    const int h0 = th * UH, w0 = tw * UW;               // first output row / column of the tile; inputs start one before
+    const int r = tid >> 5, c = tid & 31;               // gather role: output voxel (h0 + r, w0 + c), partial rows r..r+2
+    const int h = h0 + r, wq = w0 + c;
+    const bool live = r < UH && c < UW && h < H && wq < W;
+
+    float aw[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) aw[s] = (j < 27) ? w[(s + 16 * kq) * 27 + j] : 0.f;
+
+    float r1 = 0.f, r0 = 0.f;
+    stg.load(x, (size_t)n * D * H * W, H, W, h0 - 1, w0 - 1, tid, true);
+    for (int P = 0; P <= D; ++P) {
+        float q[3] = {0.f, 0.f, 0.f};
+        if (P < D) {
+            __syncthreads();                            // slice P-1: gathers done
+            stg.store(xs, tid);
+            __syncthreads();
+            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0 - 1, w0 - 1, tid, P + 1 < D);
+            f32x4 b[2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* src = xs + ((wave * 2 + i) * 32 + j) * PS + 16 * kq;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) b[i][qq] = *reinterpret_cast<const f32x4*>(src + 4 * qq);
+            }
+            __syncthreads();                            // every wave holds its fragments: xs may be overwritten with partials
+            f32x16 acc[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s], b[i][s >> 2][s & 3], acc[i], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float* dst = ts + ((wave * 2 + i) * 32 + j) * TS + 4 * kq;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[(e & 3) + 8 * (e >> 2)] = acc[i][e];
+            }
+            __syncthreads();
+            if (live) {
+                const float* t0 = ts + (r * 32 + c) * TS;
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) q[kd] += t0[(kh * 32 + kw) * TS + kd * 9 + kh * 3 + kw];
+            }
+        }
+        if (P >= 1 && live) {
+            const size_t idx = (((size_t)n * D + (P - 1)) * H + h) * W + wq;
+            float v = r1 + q[2];
+            if (add) v += add[idx];
+            y[idx] = v;
+        }
+        r1 = r0 + q[1];
+        r0 = q[0];
+    }
+}
+
 // Generic gather form of ConvTranspose3d(CI -> 1, k3, stride S, p1, op S-1); test / quarter-size path only.
 __global__ void deconv_cout1_naive_kernel(const float* __restrict__ x, const float* __restrict__ w, float bias,
                                           float* __restrict__ out, int N, int D, int H, int W, int CI, int S) {
@@ -526,12 +607,18 @@ extern "C" int msnet_conv3d_k3_cout1(const float* x, const float* w, const float
     if (!x || !w || !y) return fail("msnet_conv3d_k3_cout1: null pointer");
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_conv3d_k3_cout1: empty input");
     if (Ci != 32) return fail("msnet_conv3d_k3_cout1: Ci=%d (only 32 is built)", Ci);
-    const int nth = cdiv(H, 8), ntw = cdiv(W, 32);
     hipStream_t s = (hipStream_t)stream;
     const double vox = (double)N * D * H * W;
     LaunchScope ls("conv3d_cout1", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + vox * (add ? 2 : 1)));
+#ifdef TAIL_VALU
+    const int nth = cdiv(H, 8), ntw = cdiv(W, 32);
     hipLaunchKernelGGL((conv_cout1_kernel<32>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, add, y, N, D, H,
                        W, nth, ntw);
+#else
+    const int nth = cdiv(H, 6), ntw = cdiv(W, 30);
+    hipLaunchKernelGGL(conv_cout1_mfma_kernel, dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, add, y, N, D, H, W,
+                       nth, ntw);
+#endif
     return check_launch("msnet_conv3d_k3_cout1");
 }
 
