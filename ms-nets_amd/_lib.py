@@ -23,6 +23,7 @@ SIGNATURES = {
     "msnet_version": (c_int, []),
     "msnet_last_error": (c_char_p, []),
     "msnet_prof_enable": (c_int, [c_int]),
+    "msnet_prof_select": (c_int, [c_char_p]),
     "msnet_prof_collect": (c_long, [c_char_p, c_size_t]),
     "msnet_census": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "msnet_census_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
@@ -111,7 +112,9 @@ def require_gpu_f32(t, name, dtype=None):
     return t.contiguous()
 
 
-def prof_enable(on=True):
+def prof_enable(on=True, prefix=None):
+    """Per-launch HIP-event timing; `prefix` restricts it to kernel families whose name starts with it."""
+    load().msnet_prof_select(prefix.encode() if prefix else None)
     load().msnet_prof_enable(1 if on else 0)
 
 

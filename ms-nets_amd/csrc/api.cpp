@@ -35,9 +35,11 @@ struct Rec {
 static std::mutex g_mu;
 static std::vector<Rec*> g_recs;
 static volatile int g_prof = 0;
+static char g_prof_prefix[64] = "";      // only launches whose name starts with this are timed ("" = all)
 
 LaunchScope::LaunchScope(const char* n, hipStream_t s, double flops, double bytes) : name(n), stream(s), rec(nullptr) {
     if (!g_prof) return;
+    if (g_prof_prefix[0] && strncmp(n, g_prof_prefix, strlen(g_prof_prefix)) != 0) return;
     Rec* r = new Rec{n, nullptr, nullptr, flops, bytes};
     if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return; }
     (void)hipEventRecord(r->a, s);
@@ -61,6 +63,13 @@ extern "C" const char* msnet_last_error(void) { return g_err; }
 
 extern "C" int msnet_prof_enable(int on) {
     g_prof = on ? 1 : 0;
+    return 0;
+}
+
+extern "C" int msnet_prof_select(const char* name_prefix) {
+    if (name_prefix && strlen(name_prefix) >= sizeof(g_prof_prefix)) return fail("msnet_prof_select: prefix too long");
+    strncpy(g_prof_prefix, name_prefix ? name_prefix : "", sizeof(g_prof_prefix) - 1);
+    g_prof_prefix[sizeof(g_prof_prefix) - 1] = 0;
     return 0;
 }
 
