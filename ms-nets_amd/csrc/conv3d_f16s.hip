@@ -37,6 +37,9 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
+#ifndef S2_LOADER_WAVES
+#define S2_LOADER_WAVES 8
+#endif
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // first-class vector (HIP's uint4 is a class)
@@ -116,8 +119,10 @@ __global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* _
 // their four input planes.  The LDS plane slots rotate by two per step (logical plane p of step j lives in slot
 // (p + 2j) & 3); only the two new planes are fetched, split and copied -- into the slots of the two planes that die
 // first -- and the two-barrier staging window between tiles is empty except at the start of a column.
-template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB, int STRIDE, bool SLIDE = false>
-__global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
+// LW = loader waves (4, or 8 for the stride-2 layers whose staging work per MFMA is 2.5x that of the stride-1 layers).
+template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB, int STRIDE, bool SLIDE = false, int LW = 4>
+__global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k3s1_f16s_ws(ConvArgs a) {
+    constexpr int LT = 64 * LW;                          // loader threads
     static_assert(!SLIDE || (STRIDE == 1 && !RESB && !SWZ && TD == 2), "sliding window: stride 1, streamed weights, padded records");
     constexpr int CC = 16 * KS;
     constexpr int BH = 32 / BW;
@@ -133,7 +138,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     constexpr int NPOS = ID * IH * IW;
     constexpr int GB = 3 * KS * NB * 2 * 1024;          // bytes of one weight group
     constexpr int PG = GB / 16;                         // 16-byte pieces per weight group
-    constexpr int NLB = (PG + 255) / 256;               // pieces per loader thread per group
+    constexpr int NLB = (PG + LT - 1) / LT;               // pieces per loader thread per group
     static_assert(TD * MH * MW == 4 * MB, "M-block count mismatch");
     static_assert(NLB == 2 || NLB == 3 || NLB == 6, "weight group = 2, 3 or 6 16-byte pieces per loader thread");
     constexpr int NBUF = RESB ? 9 : 2;                  // weight-group buffers in LDS
@@ -195,23 +200,23 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         // the padding channels of its LDS records are zeroed once below and never touched again.
         constexpr int VR = RESB ? 2 : V;
         constexpr int PSLOT = IH * IW * VR;             // float4 per plane
-        constexpr int PL = (PSLOT + 255) / 256;
+        constexpr int PL = (PSLOT + LT - 1) / LT;
         static_assert(TD == 2 && (ID == 4 || ID == 5), "plane schedule below assumes TD == 2 (input planes d*S + kd)");
         f32x4 av[ID][PL];
         unsigned goff_[PL];                             // global byte offset of the slot from the plane tile origin
         int ihw_[PL];                                   // (ih << 8) | iw, or -1 for a slot past the plane's end
 #pragma unroll
         for (int u = 0; u < PL; ++u) {
-            const int slot = u * 256 + lt;
+            const int slot = u * LT + lt;
             const int pos = slot / VR, c4 = slot % VR;
             const int ih = pos / IW, iw = pos % IW;
             const bool ok = slot < PSLOT && c4 * 4 < a.Ci;      // channels beyond Ci are zero padding
             goff_[u] = (unsigned)(((ih * a.W + iw) * a.Ci + c4 * 4) * 4);
             ihw_[u] = ok ? ((ih << 8) | iw) : -1;
         }
-        // LDS offset of this thread's slot u in plane pl: voxel = pl*IH*IW + u*(256/VR) + lt/VR, channel quad c4 = lt % VR.
+        // LDS offset of this thread's slot u in plane pl: voxel = pl*IH*IW + u*(LT/VR) + lt/VR, channel quad c4 = lt % VR.
         // The swizzle term (voxel>>1)&7 does not depend on u (256/VR is a multiple of 16), only on the plane.
-        static_assert(!SWZ || ((IH * IW) % 2 == 0 && (256 / VR) % 16 == 0), "per-plane swizzle below");
+        static_assert(!SWZ || ((IH * IW) % 2 == 0 && (LT / VR) % 16 == 0), "per-plane swizzle below");
         int lhi_[ID];                                   // offset of the hi half for u = 0
 #pragma unroll
         for (int pl = 0; pl < ID; ++pl) {
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
             // in-range lanes add a positive goff_ that brings it back -- unsigned arithmetic)
             const unsigned base =
                 (unsigned)((((long)gd * a.H + ih0) * a.W + iw0) * a.Ci + c.chunk * CC) * 4u;
-            static_assert(PL * 256 >= PSLOT, "slots cover the plane");
+            static_assert(PL * LT >= PSLOT, "slots cover the plane");
             const bool plane_ok = (unsigned)gd < (unsigned)a.D;
             const bool interior = ih0 >= 0 && ih0 + IH <= a.H && iw0 >= 0 && iw0 + IW <= a.W;
 #pragma unroll
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
                 if (u < u0 || u >= u1) continue;
-                if (u * 256 + lt < PSLOT) {
+                if (u * LT + lt < PSLOT) {
                     half4 hi, lo;
 #ifdef EXP_NO_SPLIT
                     {   // diagnostic: pure copy (wrong numerics) -- what the loader costs without the split VALU work
@@ -270,7 +275,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
 #else
                     split4(av[pl][u], hi, lo);
 #endif
-                    const int off = (SLIDE ? lhi_[0] + ((pl + 2 * wrot) & 3) * (IH * IW * RB) : lhi_[pl]) + u * (256 / VR) * RB;
+                    const int off = (SLIDE ? lhi_[0] + ((pl + 2 * wrot) & 3) * (IH * IW * RB) : lhi_[pl]) + u * (LT / VR) * RB;
                     *reinterpret_cast<half4*>(lds + off) = hi;
                     *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ 64) : off + HB)) = lo;
                 }
@@ -289,20 +294,20 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
         // piece index of this thread's u-th piece (clamped for the partial last piece of a 384-piece group)
         int bi_[3];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) bi_[u] = (PG % 256 == 0 || u * 256 + lt < PG) ? u * 256 + lt : PG - 1;
+        for (int u = 0; u < 3; ++u) bi_[u] = (PG % LT == 0 || u * LT + lt < PG) ? u * LT + lt : PG - 1;
 #define MSNET_ISSUE_B(K, SET)                                                                                      \
     do {                                                                                                           \
         const u32x4* src_ = b_src(K);                                                                              \
         SET.v0 = src_[bi_[0]]; SET.v1 = src_[bi_[1]];                                                              \
         if constexpr (NLB > 2) SET.v2 = src_[bi_[2]];                                                              \
-        if constexpr (NLB > 3) { SET.v3 = src_[768 + lt]; SET.v4 = src_[1024 + lt]; SET.v5 = src_[1280 + lt]; }    \
+        if constexpr (NLB > 3) { SET.v3 = src_[3 * LT + lt]; SET.v4 = src_[4 * LT + lt]; SET.v5 = src_[5 * LT + lt]; }    \
     } while (0)
 #define MSNET_WRITE_B(K, SET)                                                                                      \
     do {                                                                                                           \
         u32x4* dst_ = reinterpret_cast<u32x4*>(lds_b + ((K) & 1) * GB);                                            \
         dst_[bi_[0]] = SET.v0; dst_[bi_[1]] = SET.v1;                                                              \
         if constexpr (NLB > 2) dst_[bi_[2]] = SET.v2;                                                              \
-        if constexpr (NLB > 3) { dst_[768 + lt] = SET.v3; dst_[1024 + lt] = SET.v4; dst_[1280 + lt] = SET.v5; }    \
+        if constexpr (NLB > 3) { dst_[3 * LT + lt] = SET.v3; dst_[4 * LT + lt] = SET.v4; dst_[5 * LT + lt] = SET.v5; }    \
     } while (0)
 #ifndef EXP_NO_GROUP_BARRIER
 #define MSNET_GROUP(G, SET)                     \
@@ -318,14 +323,14 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3s1_f16s_ws(ConvArgs a) {
 #endif
 
         if constexpr (RESB) {
-            for (int p = lt * 16; p < NPOS * RB; p += 256 * 16)      // zero the records once (padding channels stay zero)
+            for (int p = lt * 16; p < NPOS * RB; p += LT * 16)      // zero the records once (padding channels stay zero)
                 *reinterpret_cast<u32x4*>(lds + p) = u32x4{0u, 0u, 0u, 0u};
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
             // weights: one pass, all 9 groups, before the first tile is published
             for (int k = 0; k < 9; ++k) {               // (RESB is only used with a single channel group and chunk)
                 const u32x4* src = wg + (size_t)k * PG;
                 u32x4* dst = reinterpret_cast<u32x4*>(lds_b + k * GB);
-                for (int p = lt; p < PG; p += 256) dst[p] = src[p];
+                for (int p = lt; p < PG; p += LT) dst[p] = src[p];
             }
             {
                 const Coord c0 = coord_of(0);
@@ -1408,7 +1413,7 @@ static bool direct_eligible(const ConvArgs& a, size_t tiled_items) {
     return tiled_items < (size_t)num_cus() / 4;
 }
 
-template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB, int STRIDE = 1>
+template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB, int STRIDE = 1, int LW = 4>
 static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     a.ntd = cdiv(a.OD, TD); a.nth = cdiv(a.OH, TH); a.ntw = cdiv(a.OW, TW);
     a.ngroups = a.Co / (32 * NB); a.nbtot = a.Co / 32;
@@ -1420,7 +1425,7 @@ static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
                    4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB, SWZ, KS, RESB, STRIDE>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB, SWZ, KS, RESB, STRIDE, false, LW>), dim3((unsigned)nblk), dim3(256 + 64 * LW), 0, s, a);
     return check_launch(name);
 }
 
@@ -1523,7 +1528,7 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
                                              a, stride, stride == 2 ? 1 : 2, Co == 32 ? 1 : 2, s);
     }
     if (stride == 2)   // 2x2x32 output tile <- 5x5x65 input voxels x 16 channels (130 KB); 4 M-blocks, one per MFMA wave
-        return launch_f16s<2, 2, 32, 32, 1, 2, false, 1, false, 2>("conv3d_s2_f16s", a, s);
+        return launch_f16s<2, 2, 32, 32, 1, 2, false, 1, false, 2, S2_LOADER_WAVES>("conv3d_s2_f16s", a, s);
     //                                    TD TH TW  BW MB NB
     if (Ci == 8) {
         if (Co == 64) return launch_c8_f16s<2>("conv3d_s1_c8_f16s", a, s);
