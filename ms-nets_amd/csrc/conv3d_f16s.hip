@@ -37,6 +37,9 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
+#ifndef DEC_LOADER_WAVES
+#define DEC_LOADER_WAVES 4     // 8 was measured: the 168-VGPR cap of a 768-thread workgroup spills the MFMA waves (1.10 -> 2.07 ms)
+#endif
 #ifndef S2_LOADER_WAVES
 #define S2_LOADER_WAVES 8
 #endif
@@ -777,8 +780,9 @@ __global__ void pack_deconv_weight_f16s_kernel(const float* __restrict__ w, _Flo
 #else
 #define MSNET_DBAR() MSNET_LDS_BARRIER()
 #endif
-template <int KS, int NB>
-__global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
+template <int KS, int NB, int LW = 4>
+__global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
+    constexpr int LT = 64 * LW;                          // loader threads
     constexpr int TD = 2, TH = 4, TW = 32, MB = 2;
     constexpr int CI = 16 * KS;
     constexpr int ID = TD + 1, IH = TH + 1, IW = TW + 1;
@@ -787,11 +791,11 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
     constexpr int V = CI / 4;
     constexpr int NPOS = ID * IH * IW;
     constexpr int NSLOT = NPOS * V;
-    constexpr int NL = (NSLOT + 255) / 256;             // fp32 float4 per loader thread per tile
+    constexpr int NL = (NSLOT + LT - 1) / LT;             // fp32 float4 per loader thread per tile
     constexpr int GB = KS * NB * 2 * 1024;              // bytes of one weight group (one tap)
     constexpr int PG = GB / 16;
-    constexpr int NLB = PG / 256;                       // 16-byte pieces per loader thread per group
-    static_assert(PG % 256 == 0 && (NLB == 1 || NLB == 2 || NLB == 4), "weight group pieces per loader thread");
+    constexpr int NLB = PG / LT;                       // 16-byte pieces per loader thread per group
+    static_assert(PG % LT == 0 && (NLB == 1 || NLB == 2 || NLB == 4), "weight group pieces per loader thread");
     static_assert(NPOS * RB + 2 * GB <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) unsigned char lds[NPOS * RB + 2 * GB];
     unsigned char* const lds_b = lds + NPOS * RB;
@@ -833,7 +837,7 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
             asm volatile("" : "+v"(ltv));               // keep the per-slot index math inside the loop (registers)
 #pragma unroll
             for (int u = 0; u < NL; ++u) {
-                const int slot = u * 256 + ltv;
+                const int slot = u * LT + ltv;
                 const int pos = slot / V, c4 = slot % V;
                 const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
                 const bool ok = slot < NSLOT && d0 + id < a.D && h0 + ih < a.H && w0 + iw < a.W;
@@ -844,7 +848,7 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
         auto write_a = [&]() {
 #pragma unroll
             for (int u = 0; u < NL; ++u) {
-                const int slot = u * 256 + lt;
+                const int slot = u * LT + lt;
                 if (slot < NSLOT) {
                     half4 hi, lo;
                     split4(av[u], hi, lo);
@@ -875,15 +879,15 @@ __global__ __launch_bounds__(512, 2) void deconv3d_k3s2_f16s_ws(ConvArgs a) {
     do {                                                                                          \
         const u32x4* src_ = b_src(K);                                                             \
         SET.v0 = src_[0];                                                                         \
-        if constexpr (NLB > 1) SET.v1 = src_[256];                                                \
-        if constexpr (NLB > 2) { SET.v2 = src_[512]; SET.v3 = src_[768]; }                        \
+        if constexpr (NLB > 1) SET.v1 = src_[LT];                                                \
+        if constexpr (NLB > 2) { SET.v2 = src_[2 * LT]; SET.v3 = src_[3 * LT]; }                        \
     } while (0)
 #define MSNET_WRITE_B(K, SET)                                                                     \
     do {                                                                                          \
         u32x4* dst_ = reinterpret_cast<u32x4*>(lds_b + ((K) & 1) * GB) + lt;                      \
         dst_[0] = SET.v0;                                                                         \
-        if constexpr (NLB > 1) dst_[256] = SET.v1;                                                \
-        if constexpr (NLB > 2) { dst_[512] = SET.v2; dst_[768] = SET.v3; }                        \
+        if constexpr (NLB > 1) dst_[LT] = SET.v1;                                                \
+        if constexpr (NLB > 2) { dst_[2 * LT] = SET.v2; dst_[3 * LT] = SET.v3; }                        \
     } while (0)
 #if defined(DEXP_NO_B)
 #define MSNET_DGROUP(G, SET) MSNET_DBAR();
@@ -1270,7 +1274,7 @@ static int launch_deconv_f16s(const char* name, ConvArgs a, hipStream_t s) {
     const size_t nblk = nitems < (size_t)num_cus() ? nitems : (size_t)num_cus();
     const double ivox = (double)a.N * a.D * a.H * a.W;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * ivox, 4.0 * (ivox * a.Ci + 8.0 * ivox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((deconv3d_k3s2_f16s_ws<KS, NB>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((deconv3d_k3s2_f16s_ws<KS, NB, DEC_LOADER_WAVES>), dim3((unsigned)nblk), dim3(256 + 64 * DEC_LOADER_WAVES), 0, s, a);
     return check_launch(name);
 }
 
