@@ -37,6 +37,9 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
+#ifndef SLIDE_LOADER_WAVES
+#define SLIDE_LOADER_WAVES 4
+#endif
 #ifndef DEC_LOADER_WAVES
 #define DEC_LOADER_WAVES 4     // 8 was measured: the 168-VGPR cap of a 768-thread workgroup spills the MFMA waves (1.10 -> 2.07 ms)
 #endif
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     // hand-over (32 KB per CU against a store path of ~16 B/clk: ~2000 cycles during which the MFMA waves do nothing
     // else, and after the sliding window that burst IS the hand-over) but parked in `pend` and stored one element
     // per K-step under the next tile's first groups.
-    constexpr bool DRAIN = SLIDE;
+    constexpr bool DRAIN = SLIDE && LW == 4;             // (more loader waves leave no registers for the parked tile)
     constexpr int PIECES = MB * NB * 16;
     static_assert(!DRAIN || PIECES <= 9 * 3 * KS, "a tile's groups must cover the previous tile's pieces");
     f32x16 pend[DRAIN ? MB : 1][DRAIN ? NB : 1];
@@ -1468,7 +1471,7 @@ static int launch_f16s_slide(const char* name, ConvArgs a, hipStream_t s) {
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
                    4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, 32, MB, NB, false, 2, false, 1, true>), dim3((unsigned)nblk), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, 32, MB, NB, false, 2, false, 1, true, SLIDE_LOADER_WAVES>), dim3((unsigned)nblk), dim3(256 + 64 * SLIDE_LOADER_WAVES), 0, s, a);
     return check_launch(name);
 }
 
