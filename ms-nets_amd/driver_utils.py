@@ -1,0 +1,74 @@
+"""Host-side pieces of the reference's test driver that sit right after the forward pass:
+the crop of the padding added by generate_test_cbmv, the PFM writer / reader, the EPE / bad-x metric and the checkpoint
+key fix-up.  Plain NumPy -- nothing here touches the GPU; file decoding (cv2.imread) and dataset lists stay with the caller.
+
+  crop_disparity      main_msnet.py:585-589
+  save_pfm / read_pfm src/utils/pfmutil.py:86-110 / :48-83   (same bytes: header 'Pf', 'W H', signed scale, rows bottom-up)
+  get_epe_rate        main_msnet.py:708-713
+  strip_module_prefix keys saved from nn.DataParallel carry 'module.' (main_msnet.py:174, 509-526)
+"""
+import re
+import sys
+
+import numpy as np
+
+
+def crop_disparity(disp, crop_height, crop_width, height, width):
+    """disp [N, crop_height, crop_width] (or torch tensor) -> the [height, width] map of sample 0: the padding was added on
+    the TOP and the RIGHT (cbmv_generator.py:780-788), so rows crop_height-height.. and columns 0..width are kept."""
+    if hasattr(disp, "detach"):
+        disp = disp.detach().cpu().numpy()
+    if height <= crop_height and width <= crop_width:
+        return disp[0, crop_height - height: crop_height, 0:width]
+    return disp[0, :, :]
+
+
+def save_pfm(fname, image, scale=1):
+    """pfmutil.save: float32 [H,W], [H,W,1] (header 'Pf') or [H,W,3] ('PF'); rows are written bottom-up; the scale's sign
+    encodes the byte order (negative = little endian)."""
+    image = np.asarray(image)
+    if image.dtype.name != "float32":
+        raise Exception("Image dtype must be float32.")
+    if image.ndim == 3 and image.shape[2] == 3:
+        color = True
+    elif image.ndim == 2 or (image.ndim == 3 and image.shape[2] == 1):
+        color = False
+    else:
+        raise Exception("Image must have H x W x 3, H x W x 1 or H x W dimensions.")
+    endian = image.dtype.byteorder
+    if endian == "<" or (endian == "=" and sys.byteorder == "little"):
+        scale = -scale
+    with open(fname, "wb") as f:
+        f.write(b"PF\n" if color else b"Pf\n")
+        f.write(("%d %d\n" % (image.shape[1], image.shape[0])).encode("latin-1"))
+        f.write(("%f\n" % scale).encode("latin-1"))
+        np.flipud(image).tofile(f)
+
+
+def read_pfm(fname):
+    """pfmutil.readPFM: -> float32 [H, W] (single channel) or [H, W, 3], rows top-down again."""
+    with open(fname, "rb") as f:
+        kind = f.readline().decode("latin-1")
+        if "PF" in kind:
+            channels = 3
+        elif "Pf" in kind:
+            channels = 1
+        else:
+            raise ValueError("not a PFM file: %r" % kind)
+        width, height = (int(v) for v in re.findall(r"\d+", f.readline().decode("latin-1")))
+        big_endian = "-" not in f.readline().decode("latin-1")
+        data = np.frombuffer(f.read(width * height * channels * 4), dtype=(">f4" if big_endian else "<f4"))
+    shape = (height, width) if channels == 1 else (height, width, 3)
+    return np.flipud(data.reshape(shape)).astype(np.float32)
+
+
+def get_epe_rate(disp, prediction, max_disp=192, threshold=3.0):
+    """End-point error and bad-`threshold` rate over the pixels with 0.001 <= gt <= max_disp (main_msnet.py:708-713)."""
+    mask = np.logical_and(disp >= 0.001, disp <= max_disp)
+    err = np.abs(prediction[mask] - disp[mask])
+    return np.mean(err), np.sum(err > threshold) / np.sum(mask)
+
+
+def strip_module_prefix(state_dict):
+    """Checkpoints written from nn.DataParallel: 'module.conv3dbn_1.0.weight' -> 'conv3dbn_1.0.weight'."""
+    return {(k[7:] if k.startswith("module.") else k): v for k, v in state_dict.items()}
