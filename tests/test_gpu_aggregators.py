@@ -131,6 +131,37 @@ def test_conv3d_layer_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res, direc
     assert err < 5e-6
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_conv_kernels_random_ragged_shapes(gpu, hiplib, monkeypatch, seed):
+    """Random small, ragged volumes (odd depths, widths that are not multiples of 16, single rows) through every tiled
+    split-fp16 kernel family and the direct kernel: stride 1 and 2, transposed, with and without residual."""
+    from msnets_amd import hipops
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.integers(1, 3)); d = int(rng.integers(1, 8)); h = int(rng.integers(1, 14)); w = int(rng.integers(1, 71))
+    ci, co = [(32, 32), (32, 64), (64, 64), (64, 32), (64, 128), (128, 128), (8, 32), (32, 32)][seed]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((n, ci, d, h, w), generator=g) * 2
+    for direct in ("0", "1"):
+        monkeypatch.setenv("MSNET_DIRECT", direct)
+        for stride in (1, 2):
+            if not hiplib.msnet_conv3d_k3_f16s_supported(ci, co, stride):
+                continue
+            wt = torch.randn((co, ci, 3, 3, 3), generator=g) * (2.0 / (27 * ci)) ** 0.5
+            shift = torch.randn(co, generator=g) * 0.1
+            ref = F.conv3d(x.double(), wt.double(), None, stride=stride, padding=1) + shift.double().view(1, -1, 1, 1, 1)
+            res = torch.randn(ref.shape, generator=g)
+            ref = F.relu(ref + res.double())
+            wpk = hipops.pack_conv_weight(wt.cuda(), f16s=True, stride=stride)
+            y = hipops.conv3d_k3(_cl(x), wpk, None, shift.cuda(), co, stride=stride, relu=True, residual=_cl(res), f16s=True)
+            assert _rel(_nc(y).double(), ref) < 5e-6, (ci, co, stride, direct, (n, d, h, w))
+        if hiplib.msnet_deconv3d_k3s2_f16s_supported(ci, co):
+            wt = torch.randn((ci, co, 3, 3, 3), generator=g) * (2.0 / (27 * ci)) ** 0.5
+            ref = F.conv_transpose3d(x.double(), wt.double(), None, stride=2, padding=1, output_padding=1)
+            wpk = hipops.pack_conv_weight(wt.cuda(), transposed=True, f16s=True)
+            y = hipops.deconv3d_k3s2(_cl(x), wpk, None, None, co, relu=False, residual=None, f16s=True)
+            assert _rel(_nc(y).double(), ref) < 5e-6, (ci, co, "deconv", direct, (n, d, h, w))
+
+
 @pytest.mark.parametrize("dims,seg", [((1, 12, 9, 70), 1), ((1, 12, 9, 70), 3), ((2, 8, 16, 33), 2), ((1, 16, 5, 32), 4),
                                       ((1, 6, 4, 32), 1)])
 @pytest.mark.parametrize("use_res", [False, True])
