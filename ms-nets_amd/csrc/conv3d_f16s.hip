@@ -115,7 +115,7 @@ __global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* _
 
 // SWZ = false: 144-byte voxel records (16 B pad): with 1x32-voxel M-blocks every ds_read_b128 lane group hits 16
 //               distinct bank slots and all fragment addresses are base + immediate (no VALU in the MFMA stream).
-// SWZ = true : 128-byte records with the 16-byte slots XOR-swizzled by (voxel>>1)&7 -- same conflict-freeness in
+// SWZ = true : 128-byte records with the 16-byte slots XOR-swizzled by (tile column >> 1) & 7 -- same conflict-freeness in
 //               13 KB less LDS (what lets the Co=64 weight double buffer fit), at ~6 VALU per fragment address.
 // KS = 16-channel K-steps per staged chunk: 2 (32-channel chunks) or 1 (the 8-channel first layer, zero-padded to 16).
 // RESB = true: all 27 taps of the (single-chunk) weight tensor stay resident in LDS for the whole kernel -- used when
@@ -221,14 +221,24 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             ihw_[u] = ok ? ((ih << 8) | iw) : -1;
         }
         // LDS offset of this thread's slot u in plane pl: voxel = pl*IH*IW + u*(LT/VR) + lt/VR, channel quad c4 = lt % VR.
-        // The swizzle term (voxel>>1)&7 does not depend on u (256/VR is a multiple of 16), only on the plane.
-        static_assert(!SWZ || ((IH * IW) % 2 == 0 && (LT / VR) % 16 == 0), "per-plane swizzle below");
-        int lhi_[ID];                                   // offset of the hi half for u = 0
+        // Swizzled records: the 16-byte slot is XORed with (iw >> 1) & 7, iw = the voxel's COLUMN in the tile.  (Keying on the
+        // linear voxel index instead made the two 16-voxel rows of a 2x16 M-block -- 18 voxels apart -- collide on two of the
+        // 16 slots in every ds_read_b128 lane group: 31 % of the LDS cycles of the 2x8x16 kernel were conflict cycles.)
+        static_assert(!SWZ || (IW % 2 == 0), "an even row pitch keeps record parity = column parity");
+        int lhi_[ID];                                   // offset of the hi half for u = 0 (padded records)
+        int lsw_[SWZ ? PL : 1];                         // swizzled records: in-plane offset of slot u, swizzle included
 #pragma unroll
         for (int pl = 0; pl < ID; ++pl) {
             const int p0 = lt / VR, c4 = lt % VR;
-            const int sw = SWZ ? (((p0 >> 1) + pl * (IH * IW / 2)) & 7) : 0;
-            lhi_[pl] = (pl * IH * IW + p0) * RB + (c4 & 1) * 8 + (((c4 >> 1) ^ sw) << 4);
+            lhi_[pl] = (pl * IH * IW + p0) * RB + (c4 & 1) * 8 + ((c4 >> 1) << 4);
+        }
+        if constexpr (SWZ) {
+#pragma unroll
+            for (int u = 0; u < PL; ++u) {
+                const int pos = u * (LT / VR) + lt / VR, c4 = lt % VR;
+                const int key = ((pos % IW) >> 1) & 7;
+                lsw_[u] = pos * RB + (c4 & 1) * 8 + (((c4 >> 1) ^ key) << 4);
+            }
         }
         const size_t sample_bytes = (size_t)a.D * a.H * a.W * a.Ci * 4;
 
@@ -281,7 +291,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #else
                     split4(av[pl][u], hi, lo);
 #endif
-                    const int off = (SLIDE ? lhi_[0] + ((pl + 2 * wrot) & 3) * (IH * IW * RB) : lhi_[pl]) + u * (LT / VR) * RB;
+                    const int off = SWZ ? pl * (IH * IW * RB) + lsw_[u]
+                                        : (SLIDE ? lhi_[0] + ((pl + 2 * wrot) & 3) * (IH * IW * RB) : lhi_[pl]) + u * (LT / VR) * RB;
                     *reinterpret_cast<half4*>(lds + off) = hi;
                     *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ 64) : off + HB)) = lo;
                 }
@@ -477,12 +488,14 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     const int wm = wave;                                // WM = 4, WN = 1
     const int r = lane & 31, hh = lane >> 5;
     int vox0[MB];                                       // LDS voxel index of this lane's output voxel (tap 0,0,0)
+    [[maybe_unused]] int lwv[MB];
 #pragma unroll
     for (int i = 0; i < MB; ++i) {
         const int mb = wm * MB + i;
         const int bw_ = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
         const int lh = bh * BH + r / BW, lw = bw_ * BW + r % BW;
         vox0[i] = ((SLIDE ? 0 : bd * STRIDE * IH) + lh * STRIDE) * IW + lw * STRIDE;    // SLIDE: the plane comes from grp_off
+        lwv[i] = lw * STRIDE;                           // tile column of the lane's voxel at kw = 0 (swizzle key)
     }
     int rot = 0;                                        // SLIDE: plane-slot rotation of the current item
     // voxel offset of group g's (kd, kh) row for M-block i
@@ -619,7 +632,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 const int goff = goffs[i];
                 if (SWZ) {
                     const int vox = vox0[i] + goff + t;
-                    const int off = vox * RB + (((ks * 2 + hh) ^ ((vox >> 1) & 7)) << 4);
+                    const int off = vox * RB + (((ks * 2 + hh) ^ (((lwv[i] + t) >> 1) & 7)) << 4);
                     ah[slot][i] = *reinterpret_cast<const half8*>(lds + off);
                     al[slot][i] = *reinterpret_cast<const half8*>(lds + (off ^ 64));
                 } else {
