@@ -226,18 +226,26 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         // 16 slots in every ds_read_b128 lane group: 31 % of the LDS cycles of the 2x8x16 kernel were conflict cycles.)
         static_assert(!SWZ || (IW % 2 == 0), "an even row pitch keeps record parity = column parity");
         int lhi_[ID];                                   // offset of the hi half for u = 0 (padded records)
-        int lsw_[SWZ ? PL : 1];                         // swizzled records: in-plane offset of slot u, swizzle included
+        // Stride 2: a lane's voxels are two columns apart, and with 16-byte-aligned records any padded layout then puts 16
+        // lanes on 8 distinct bank slots (2-way conflict on every A read: 27 % of the kernel's LDS cycles).  The columns of a
+        // tile row are therefore stored de-interleaved -- even columns first, then the odd ones -- so that a tap reads
+        // consecutive records again (tap kw: parity kw & 1, start kw >> 1).
+        constexpr bool CPERM = STRIDE == 2 && !SWZ;
+        constexpr int CHALF = (IW + 1) / 2;
+        int lsw_[(SWZ || CPERM) ? PL : 1];              // in-plane LDS offset of slot u (swizzle / column permutation included)
 #pragma unroll
         for (int pl = 0; pl < ID; ++pl) {
             const int p0 = lt / VR, c4 = lt % VR;
             lhi_[pl] = (pl * IH * IW + p0) * RB + (c4 & 1) * 8 + ((c4 >> 1) << 4);
         }
-        if constexpr (SWZ) {
+        if constexpr (SWZ || CPERM) {
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
-                const int pos = u * (LT / VR) + lt / VR, c4 = lt % VR;
-                const int key = ((pos % IW) >> 1) & 7;
-                lsw_[u] = pos * RB + (c4 & 1) * 8 + (((c4 >> 1) ^ key) << 4);
+                const int slot = u * LT + lt, pos = slot / VR, c4 = slot % VR;
+                const int ih = pos / IW, iw = pos % IW;
+                const int key = SWZ ? ((iw >> 1) & 7) : 0;
+                const int col = CPERM ? (iw & 1) * CHALF + (iw >> 1) : iw;
+                lsw_[u] = (ih * IW + col) * RB + (c4 & 1) * 8 + (((c4 >> 1) ^ key) << 4);
             }
         }
         const size_t sample_bytes = (size_t)a.D * a.H * a.W * a.Ci * 4;
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #else
                     split4(av[pl][u], hi, lo);
 #endif
-                    const int off = SWZ ? pl * (IH * IW * RB) + lsw_[u]
+                    const int off = (SWZ || CPERM) ? pl * (IH * IW * RB) + lsw_[u]
                                         : (SLIDE ? lhi_[0] + ((pl + 2 * wrot) & 3) * (IH * IW * RB) : lhi_[pl]) + u * (LT / VR) * RB;
                     *reinterpret_cast<half4*>(lds + off) = hi;
                     *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ 64) : off + HB)) = lo;
@@ -494,7 +502,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         const int mb = wm * MB + i;
         const int bw_ = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
         const int lh = bh * BH + r / BW, lw = bw_ * BW + r % BW;
-        vox0[i] = ((SLIDE ? 0 : bd * STRIDE * IH) + lh * STRIDE) * IW + lw * STRIDE;    // SLIDE: the plane comes from grp_off
+        // SLIDE: the plane comes from grp_off.  Stride 2 with de-interleaved columns: output column lw reads record lw of
+        // the even half (kw = 0, 2) or of the odd half (kw = 1), see tap_col below.
+        vox0[i] = ((SLIDE ? 0 : bd * STRIDE * IH) + lh * STRIDE) * IW + ((STRIDE == 2 && !SWZ) ? lw : lw * STRIDE);
         lwv[i] = lw * STRIDE;                           // tile column of the lane's voxel at kw = 0 (swizzle key)
     }
     int rot = 0;                                        // SLIDE: plane-slot rotation of the current item
@@ -636,7 +646,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                     ah[slot][i] = *reinterpret_cast<const half8*>(lds + off);
                     al[slot][i] = *reinterpret_cast<const half8*>(lds + (off ^ 64));
                 } else {
-                    const unsigned char* p = lds + (vox0[i] + goff) * RB + 16 * hh + t * RB + ks * 32;
+                    constexpr int CH = (IW + 1) / 2;
+                    const int tcol = (STRIDE == 2) ? (t & 1) * CH + (t >> 1) : t;      // record offset of tap kw = t
+                    const unsigned char* p = lds + (vox0[i] + goff) * RB + 16 * hh + tcol * RB + ks * 32;
                     ah[slot][i] = *reinterpret_cast<const half8*>(p);
                     al[slot][i] = *reinterpret_cast<const half8*>(p + HB);
                 }
