@@ -21,6 +21,18 @@
 
 namespace msnet {
 
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+// x = hi + lo * 2^-11 with hi = fp16(x), lo = fp16((x - hi) * 2^11): the operand split of the conv kernels
+__device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, half8_t& hi, half8_t& lo) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float v = k < 4 ? a[k] : b[k - 4];
+        const _Float16 h = (_Float16)v;
+        hi[k] = h;
+        lo[k] = (_Float16)((v - (float)h) * 2048.f);
+    }
+}
+
 // Online softmax state for sum_d d * softmax(x)_d.
 struct SoftArg {
     float m, s, t;
@@ -227,9 +239,25 @@ __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const
     const bool live = r < UH && c < UW && h < H && wq < W;
     const int OH = 2 * H, OW = 2 * W;
 
+#ifdef TAIL_FP32_MFMA
     float aw[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) aw[s] = (j < 27) ? w[(s + 16 * kq) * 27 + j] : 0.f;
+#else
+    // split-fp16 form of the same product (3 x v_mfma_f32_32x32x16_f16 per 16 channels instead of 8 x 32x32x2_f32: the fp32
+    // MFMAs kept the matrix pipe busy 40 % of this kernel).  K-step s, lane half kq: channels 16 s + 8 kq .. + 7.
+    half8_t wh[2], wl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        f32x4 a4, b4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a4[k] = (j < 27) ? w[(16 * s + 8 * kq + k) * 27 + j] : 0.f;
+            b4[k] = (j < 27) ? w[(16 * s + 8 * kq + 4 + k) * 27 + j] : 0.f;
+        }
+        split8(a4, b4, wh[s], wl[s]);
+    }
+#endif
 
     SoftArg sa[4];
 #pragma unroll
@@ -247,7 +275,10 @@ __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const
             __syncthreads();                            // slice P-1: gathers done, xs free
             stg.store(xs, tid);
             __syncthreads();
+#ifdef TAIL_FP32_MFMA
             stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0, w0, tid, P + 1 < D);   // in flight during the MFMAs
+#endif
+#ifdef TAIL_FP32_MFMA
             f32x4 b[2][4];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -266,12 +297,47 @@ __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s], b[i][s >> 2][s & 3], acc[i], 0, 0, 0);
+#else
+            f32x4 b[2][4];                              // [M-block][K-step s: quads 2s, 2s+1] = channels 16 s + 8 kq .. + 7
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float* src = xs + ((wave * 2 + i) * 32 + j) * PS + 8 * kq;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    b[i][2 * s] = *reinterpret_cast<const f32x4*>(src + 16 * s);
+                    b[i][2 * s + 1] = *reinterpret_cast<const f32x4*>(src + 16 * s + 4);
+                }
+            }
+            __syncthreads();                            // every wave holds its fragments: xs may be overwritten with partials
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                f32x16 a0, a1;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    half8_t xh, xl;
+                    split8(b[i][2 * s], b[i][2 * s + 1], xh, xl);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xh, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], xh, a1, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xl, a1, 0, 0, 0);
+                }
+                float* dst = ts + ((wave * 2 + i) * 32 + j) * TS + 4 * kq;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) dst[(e & 3) + 8 * (e >> 2)] = a0[e] + a1[e] * (1.f / 2048.f);
+            }
+            // the next slice is requested only now: its 32 registers would otherwise sit under the MFMA phase and cost the third
+            // resident workgroup; the gather, the softmax and the other workgroups' phases cover the latency
+            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0, w0, tid, P + 1 < D);
+#endif
+#ifdef TAIL_FP32_MFMA
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 float* dst = ts + ((wave * 2 + i) * 32 + j) * TS + 4 * kq;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) dst[(e & 3) + 8 * (e >> 2)] = acc[i][e];
             }
+#endif
             __syncthreads();
             if (live) {
                 const float* t0 = ts + (r * 32 + c) * TS;
