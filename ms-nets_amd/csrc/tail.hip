@@ -438,7 +438,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict
     }
 }
 
-// The same head with the channel contraction on the fp32 MFMA (see deconv5_tail_mfma_kernel): per input slice every voxel's
+// The same head with the channel contraction on the split-fp16 MFMA (see deconv5_tail_mfma_kernel): per input slice every voxel's
 // 27 tap partials T[voxel][tap] are computed once, parked in LDS, and each output voxel (h, w) adds, for kd = 0,1,2, the nine
 // partials T[(h+kh-1, w+kw-1)][kd,kh,kw] of its 3x3 neighbourhood; kd = 2 finishes out[P-1], kd = 1 goes to out[P], kd = 0 to
 // out[P+1].  A workgroup multiplies 8 x 32 input voxels per slice (origin h0-1, w0-1) and finishes the inner 6 x 30 outputs.
@@ -460,9 +460,17 @@ __global__ __launch_bounds__(256) void conv_cout1_mfma_kernel(const float* __res
     const int h = h0 + r, wq = w0 + c;
     const bool live = r < UH && c < UW && h < H && wq < W;
 
-    float aw[16];
+    half8_t wh[2], wl[2];                               // split-fp16 weights: K-step s, lane half kq: channels 16 s + 8 kq .. + 7
 #pragma unroll
-    for (int s = 0; s < 16; ++s) aw[s] = (j < 27) ? w[(s + 16 * kq) * 27 + j] : 0.f;
+    for (int s = 0; s < 2; ++s) {
+        f32x4 a4, b4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            a4[k] = (j < 27) ? w[(16 * s + 8 * kq + k) * 27 + j] : 0.f;
+            b4[k] = (j < 27) ? w[(16 * s + 8 * kq + 4 + k) * 27 + j] : 0.f;
+        }
+        split8(a4, b4, wh[s], wl[s]);
+    }
 
     float r1 = 0.f, r0 = 0.f;
     stg.load(x, (size_t)n * D * H * W, H, W, h0 - 1, w0 - 1, tid, true);
@@ -472,31 +480,35 @@ __global__ __launch_bounds__(256) void conv_cout1_mfma_kernel(const float* __res
             __syncthreads();                            // slice P-1: gathers done
             stg.store(xs, tid);
             __syncthreads();
-            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0 - 1, w0 - 1, tid, P + 1 < D);
-            f32x4 b[2][4];
+            f32x4 b[2][4];                              // [M-block][K-step s: quads 2s, 2s+1]
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float* src = xs + ((wave * 2 + i) * 32 + j) * PS + 16 * kq;
+                const float* src = xs + ((wave * 2 + i) * 32 + j) * PS + 8 * kq;
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) b[i][qq] = *reinterpret_cast<const f32x4*>(src + 4 * qq);
+                for (int s = 0; s < 2; ++s) {
+                    b[i][2 * s] = *reinterpret_cast<const f32x4*>(src + 16 * s);
+                    b[i][2 * s + 1] = *reinterpret_cast<const f32x4*>(src + 16 * s + 4);
+                }
             }
             __syncthreads();                            // every wave holds its fragments: xs may be overwritten with partials
-            f32x16 acc[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-#pragma unroll
-            for (int s = 0; s < 16; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(aw[s], b[i][s >> 2][s & 3], acc[i], 0, 0, 0);
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
+                f32x16 a0, a1;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    half8_t xh, xl;
+                    split8(b[i][2 * s], b[i][2 * s + 1], xh, xl);
+                    a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xh, a0, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[s], xh, a1, 0, 0, 0);
+                    a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[s], xl, a1, 0, 0, 0);
+                }
                 float* dst = ts + ((wave * 2 + i) * 32 + j) * TS + 4 * kq;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) dst[(e & 3) + 8 * (e >> 2)] = acc[i][e];
+                for (int e = 0; e < 16; ++e) dst[(e & 3) + 8 * (e >> 2)] = a0[e] + a1[e] * (1.f / 2048.f);
             }
+            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0 - 1, w0 - 1, tid, P + 1 < D);   // after the MFMA phase (registers)
             __syncthreads();
             if (live) {
                 const float* t0 = ts + (r * 32 + c) * TS;
