@@ -7,16 +7,22 @@
         bench.py --gpus N --steps K --warmup W
 
 One step = one pass of the hot path over one batch of synthetic stereo pairs already resident in HBM:
-  two bordered uint8 half-res images -> HIP matching-space volume [8,96,272,480] -> HIP MS-GCNet (19 3-D
-  convs on the fp32-input MFMA) -> fused deconv5+soft-argmin -> disparity [544,960]; for N>1 an RCCL all-gather
-  of the per-rank maps closes the step.  Weak scaling: every rank processes --batch-per-gpu pairs per step.
+  two bordered uint8 half-res images -> HIP matching-space volume [8,96,272,480] -> HIP MS-GCNet (19 3-D convs; by default
+  on the split-fp16 MFMA path: every fp32 operand as fp16 hi + fp16 lo, three fp16 MFMAs per product, fp32 accumulate;
+  --precision fp32 runs them on the fp32-input MFMA) -> fused deconv5 + soft-argmin -> disparity [544,960]; for N>1 an
+  RCCL all-gather of the per-rank maps closes the step.  Weak scaling: every rank processes --batch-per-gpu pairs per step.
 
 Rank 0 prints ONE JSON line (contract in the task statement) extended with
-  roofline     : the dominant kernel (stride-1 MFMA conv3d) -- algorithmic FLOPs / HIP-event time, vs the
-                 155-157 TFLOP/s fp32-matrix peak of MI355X (MI355X_MICROARCH.md);
-  cpu_baseline : the CPU oracle (a port, not the reference binary) timed on this host on a bounded sample.
+  roofline        : the dominant kernel (conv3dbn_2's stride-1 conv) -- algorithmic FLOPs / HIP-event time vs the dense fp16
+                    MFMA peak / 3 (vendor) and vs the MFMA rate measured on this device by a register-only loop;
+  roofline_volume : the matching-space volume build, HBM-bound -- 401.4 MB algorithmic per map / sum of its kernels' HIP-event
+                    times vs 8 TB/s (vendor) and vs a float4 copy measured on this device;
+  step_ms         : median / p10 / p90 of the K per-step times (HIP events between the steps of the timed region);
+  fp32_exact      : the same step timed again with every conv on the exact fp32-input MFMA (the reference's arithmetic);
+  cpu_baseline    : the CPU oracle (a port, not the reference binary) timed on this host on a bounded sample.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -30,7 +36,9 @@ import torch
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)", spec; 155 measured
 FP16_MATRIX_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md "HBM3E peak BW" (spec); 6290 measured there with a float4 copy
 SPLIT_MFMAS_PER_PRODUCT = 3         # split-fp16: ah*wh, al*wh, ah*wl  
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
 WORKLOADS = {
     # name: (padded H, W, maxdisp, description)
     "cfg2": (544, 960, 192, "MS-GCNet forward (MS volume build + 19-conv aggregator + soft-argmin), Scene-Flow "
@@ -40,6 +48,7 @@ WORKLOADS = {
     "cfg3": (544, 960, 192, "PSMNet-style aggregator forward on a random [64, D/4, H/4, W/4] volume (module as released), "
                             "960x540 padded to 960x544, D=192 -- NOT the headline metric"),
 }
+VOLUME_FAMILIES = ("vol_",)
 
 
 def gcnet_flops(H, W, D):
@@ -55,42 +64,101 @@ def gcnet_flops(H, W, D):
     return 2.0 * mac
 
 
-def pmc_traffic(kernel_name):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as
-    MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE as is; both in KB) -- measured once per round on the same
-    workload with tools_pmc.sh, not re-measured by the timed run.  None if no measurement is committed."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_dominant.json")
+def _source_sha(*names):
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(ROOT, "ms-nets_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(key, workload, batch):
+    """HBM bytes per launch / per map from the committed rocprofv3 PMC passes (FETCH_SIZE doubled as MI355X_MICROARCH.md
+    prescribes for wide coalesced reads on gfx950, WRITE_SIZE as is) -- measured with tools/tools_pmc_bench.sh on the same
+    workload, not by the timed run.  Returned only if it was measured on this workload, this batch size and THIS kernel source
+    (sha256 of the .hip files it names); otherwise None."""
     try:
-        d = json.load(open(path))
-        return d["hbm_bytes_per_launch"] if d.get("kernel_key") in kernel_name else None
+        rec = json.load(open(PMC_FILE))[key]
+        if rec.get("workload") != workload or rec.get("batch_per_gpu") != batch:
+            return None
+        if rec.get("source_sha16") != _source_sha(*rec["sources"]):
+            return None
+        return rec["hbm_bytes"]
     except Exception:
         return None
 
 
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(seed=0):
-    """The oracle (CPU port of the same path: C matchers + NumPy glue + torch fp32 aggregator) on a bounded
-    sample: ONE full cfg#2 map (272x480 half-res, D'=96), single run, no warm-up.  Throughput is
-    scaled to full maps by the voxel ratio (every stage is linear in H'*W')."""
+    """The oracle (CPU port of the same path: C matchers + NumPy glue + torch fp32 aggregator) on a bounded sample: one
+    warm-up on a 32x64 crop (pages in the libraries and oneDNN's primitives), then ONE full cfg#2 map (272x480 half-res,
+    D'=96)."""
     from msnets_amd import synthetic
     from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre
     from oracle import aggregators, ms_volume
-    hs, ws, nd = 272, 480, 96
     cores = min(os.cpu_count() or 1, 64)     # MKL-DNN conv3d stops scaling (and regresses) far below 256 threads
     torch.set_num_threads(cores)
     os.environ.setdefault("OMP_NUM_THREADS", str(cores))
-    left, right, _ = synthetic.stereo_pair(hs, ws, nd, seed=seed)
     torch.manual_seed(0)
-    sd = GCNet_CostVolumeAggre(2 * nd).eval().state_dict()
-    t0 = time.time()
-    vol = ms_volume.build_ms_volume(left, right, nd)
-    t1 = time.time()
-    with torch.no_grad():
-        aggregators.gcnet_forward(sd, torch.from_numpy(vol).unsqueeze(0), 2 * nd)
-    t2 = time.time()
-    scale = (272 * 480) / float(hs * ws)
-    return {"value": 1.0 / ((t2 - t0) * scale), "unit": "maps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "oracle volume build (%.1fs) + torch-CPU fp32 GCNet forward (%.1fs) on a %dx%d half-res crop "
-                      "at D'=96, scaled x%.2f to 272x480" % (t1 - t0, t2 - t1, hs, ws, scale)}
+    sd = GCNet_CostVolumeAggre(192).eval().state_dict()
+
+    def run(hs, ws, nd):
+        left, right, _ = synthetic.stereo_pair(hs, ws, nd, seed=seed)
+        t0 = time.time()
+        vol = ms_volume.build_ms_volume(left, right, nd)
+        t1 = time.time()
+        with torch.no_grad():
+            aggregators.gcnet_forward(sd, torch.from_numpy(vol).unsqueeze(0), 2 * nd)
+        return t1 - t0, time.time() - t1
+
+    run(32, 64, 96)
+    tv, ta = run(272, 480, 96)
+    return {"value": 1.0 / (tv + ta), "unit": "maps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu_model": _cpu_model(),
+            "sample": "one full map after a 32x64 warm-up: oracle volume build %.1fs + torch-CPU fp32 GCNet forward %.1fs "
+                      "at 272x480 half-res, D'=96" % (tv, ta)}
+
+
+def measure_peaks(dev):
+    """Attainable peaks of THIS device: float4 copy (GB/s of read + write) and register-only fp16 MFMA loop (TFLOP/s)."""
+    from msnets_amd import _lib
+    lib = _lib.load()
+    n = 1 << 30
+    src = torch.empty(n, device=dev, dtype=torch.uint8)
+    dst = torch.empty(n, device=dev, dtype=torch.uint8)
+    src.fill_(1)
+    ev = lambda: torch.cuda.Event(enable_timing=True)       # noqa: E731
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(reps):
+            a, b = ev(), ev()
+            a.record()
+            fn()
+            b.record()
+            torch.cuda.synchronize()
+            t = a.elapsed_time(b)
+            best = t if best is None else min(best, t)
+        return best
+
+    t_copy = timed(lambda: _lib.check(lib.msnet_peak_copy(_lib.ptr(src), _lib.ptr(dst), n, _lib.stream_ptr()), "msnet_peak_copy"), 5)
+    flops = [0.0]
+
+    def mfma():
+        flops[0] = lib.msnet_peak_mfma_f16(_lib.ptr(dst), 40000, _lib.stream_ptr())
+    t_mfma = timed(mfma, 3)
+    return {"hbm_copy_GBs": 2.0 * n / t_copy / 1e6, "mfma_f16_TFLOPs": flops[0] / t_mfma / 1e9}
 
 
 def main():
@@ -101,6 +169,7 @@ def main():
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch-per-gpu", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the fp32_exact loop and the peak micro-benchmarks")
     ap.add_argument("--no-volume", action="store_true", help="aggregator only (random volume), not the headline")
     ap.add_argument("--precision", default="split-fp16", choices=["split-fp16", "fp32"])
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-launch HIP events (diagnostic)")
@@ -144,12 +213,14 @@ def main():
         if args.no_volume:
             vol.copy_(synthetic.random_volume(tuple(vol.shape), seed=rank).to(dev))
 
-    def step():
+    def local_step():
         if not args.no_volume:
             for b, (l, r) in enumerate(pairs):
                 builder(l, r, out=vol[b])
-        disp = model(vol)
-        return msdist.gather_disparities(disp, n_total)
+        return model(vol)
+
+    def step():
+        return msdist.gather_disparities(local_step(), n_total)
 
     # Setup (untimed, not part of the W warm-up steps): the first forward packs the weights into MFMA order and the next
     # one or two let torch's caching allocator reach its steady-state pool (the path allocates ~6 GB of activations per
@@ -162,27 +233,38 @@ def main():
         out = step()
         torch.cuda.synchronize()
 
+    # Outside the timed region: the gathered batch must be the per-rank maps in sample order (sample i from rank i % world).
+    mine = local_step()
+    gathered = msdist.gather_disparities(mine, n_total)
+    for j, i in enumerate(msdist.shard_indices(n_total, rank, world)):
+        assert torch.equal(gathered[i], mine[j]), "all-gather order: sample %d is not rank %d's map %d" % (i, rank, j)
+    del mine, gathered
+
     for _ in range(args.warmup):
         out = step()
     torch.cuda.synchronize()
     assert out.shape == (n_total, H, W) and bool(torch.isfinite(out).all())
 
-    # HIP events around the launches of the dominant kernel family only (all families with --verbose): the two event
-    # records per launch cost host time, 0.18 ms per step (2 %) when all ~45 launches of a forward are timed.
-    dom_prefix = None if args.verbose else ("conv3d_s1_f16s_co32" if args.precision != "fp32" and args.workload != "cfg3"
-                                            else "conv3d_s1")
+    # HIP events around the launches of the dominant kernel family and the volume-build kernels only (all families with
+    # --verbose): the two event records per launch cost host time, 0.18 ms per step (2 %) when all ~45 launches are timed.
+    dom_family = "conv3d_s1_f16s_co32" if args.precision != "fp32" and args.workload != "cfg3" else "conv3d_s1"
+    dom_prefix = None if args.verbose else ",".join((dom_family,) + VOLUME_FAMILIES)
     _lib.prof_enable(not args.no_kernel_timing, dom_prefix)
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     msdist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    step_ev[0].record()
+    for k in range(args.steps):
         out = step()
+        step_ev[k + 1].record()
     torch.cuda.synchronize()
     msdist.barrier()
     dt = time.perf_counter() - t0
     _lib.prof_enable(False)
     prof = _lib.prof_collect()
     all_timed = dom_prefix is None and not args.no_kernel_timing
+    per_step = sorted(step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps))
 
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -191,6 +273,7 @@ def main():
 
     if rank == 0:
         maps = n_total * args.steps
+        pct = lambda q: float(np.percentile(per_step, q))      # noqa: E731
         # dominant kernel = the stride-1 conv3d family: split-fp16 MFMA when that precision is active, else fp32 MFMA
         f16 = {k: v for k, v in prof.items() if k.startswith("conv3d_s1_f16s")}
         if f16:
@@ -199,10 +282,11 @@ def main():
             dom_name, dom = "conv3d_k3s1_f16s_ws / %s (split-fp16 MFMA, 3 MFMAs per product)" % key, f16[key]
             peak = FP16_MATRIX_PEAK_TFLOPS / SPLIT_MFMAS_PER_PRODUCT
             peak_note = "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product"
+            mfmas = SPLIT_MFMAS_PER_PRODUCT
         else:
             dom_name, dom = "conv3d_k3_mfma_ws (fp32-input MFMA, stride-1 launches)", prof.get(
                 "conv3d_s1", {"ms": 0.0, "flops": 0.0, "calls": 0})
-            peak, peak_note = FP32_MATRIX_PEAK_TFLOPS, "fp32-input MFMA peak"
+            peak, peak_note, mfmas = FP32_MATRIX_PEAK_TFLOPS, "fp32-input MFMA peak", None
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
         conv_ms = sum(v["ms"] for k, v in prof.items() if k.startswith(("conv3d", "deconv3d")))
         conv_fl = sum(v["flops"] for k, v in prof.items() if k.startswith(("conv3d", "deconv3d")))
@@ -216,13 +300,26 @@ def main():
             "config": {"workload": desc + ", batch=%d per GPU" % B, "global_batch": n_total,
                        "parallelism": "dp%d (rank-sharded pairs, RCCL all-gather of disparity maps)" % world,
                        "includes_volume_build": not args.no_volume},
+            "step_ms": {"median": pct(50), "p10": pct(10), "p90": pct(90), "source": "HIP events between steps, rank 0"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s", "frac": achieved / peak,
                          "time_share_of_step": dom["ms"] / (1e3 * dt) if dt > 0 else 0.0,
                          "launches": dom["calls"], "avg_launch_ms": dom["ms"] / max(1, dom["calls"]),
                          "all_conv_tflops": (conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0) if all_timed else None,
-                         "traffic": pmc_traffic(dom_name)},
+                         "traffic": pmc_traffic(dom_family, args.workload, B)},
         }
+        volk = {k: v for k, v in prof.items() if k.startswith(VOLUME_FAMILIES)}
+        if volk and not args.no_volume:
+            vms = sum(v["ms"] for v in volk.values())
+            alg_bytes = 4.0 * 8 * nd * hh * wh + 2.0 * (hh + 20) * (wh + 20)        # 401.4 MB at cfg#2
+            builds = maps / world
+            gbs = alg_bytes * builds / (vms * 1e-3) / 1e9 if vms > 0 else 0.0
+            line["roofline_volume"] = {
+                "bound": "hbm", "kernel": "msnet_build_volume: " + " + ".join(sorted(volk)), "achieved": gbs, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_map": alg_bytes,
+                "us_per_map": 1e3 * vms / builds,
+                "us_per_map_by_kernel": {k: 1e3 * v["ms"] / builds for k, v in sorted(volk.items())},
+                "traffic": pmc_traffic("volume_build", args.workload, B)}
         if args.verbose:
             tot = sum(v["ms"] for v in prof.values())
             for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"]):
@@ -231,6 +328,32 @@ def main():
                 print("  %-22s calls %4d  %9.3f ms/step (%5.1f%%)  %7.1f TFLOP/s  %8.1f GB/s(alg)" % (
                     k, v["calls"], v["ms"] / args.steps, 100 * v["ms"] / tot, tf, gb), file=sys.stderr)
             print("  kernels %.3f ms/step of %.3f ms/step wall" % (tot / args.steps, 1e3 * dt / args.steps), file=sys.stderr)
+        if world == 1 and not args.no_extras:
+            pk = measure_peaks(dev)
+            line["peaks_measured"] = dict(pk, note="this device, this run: float4 copy of 1 GiB (read + write bytes) and a "
+                                                   "register-only v_mfma_f32_32x32x16_f16 loop on non-zero operands, best of 3-5")
+            if mfmas:
+                att = pk["mfma_f16_TFLOPs"] / mfmas
+                line["roofline"]["peak_attainable"] = att
+                line["roofline"]["frac_attainable"] = achieved / att if att > 0 else None
+            if "roofline_volume" in line:
+                line["roofline_volume"]["peak_attainable"] = pk["hbm_copy_GBs"]
+                line["roofline_volume"]["frac_attainable"] = line["roofline_volume"]["achieved"] / pk["hbm_copy_GBs"]
+            if args.precision != "fp32" and args.workload != "cfg3":
+                # a driver-timed number at the reference's own arithmetic: every conv on the exact fp32-input MFMA
+                hipops.set_default_precision("fp32")
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                k32 = max(3, min(5, args.steps))
+                t1 = time.perf_counter()
+                for _ in range(k32):
+                    step()
+                torch.cuda.synchronize()
+                d32 = time.perf_counter() - t1
+                hipops.set_default_precision(args.precision)
+                line["fp32_exact"] = {"value": n_total * k32 / d32, "unit": "maps/s", "ms_per_step": 1e3 * d32 / k32, "steps": k32,
+                                      "dtype": "f32 (exact fp32-input MFMA in every conv)"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)

@@ -37,10 +37,18 @@ const char* msnet_last_error(void);
  * "name calls total_ms flops bytes\n" per kernel into buf (returns bytes written, <0 on error) and
  * clears the log. */
 int         msnet_prof_enable(int on);
-/* Restrict the timing to launches whose kernel-family name starts with `name_prefix` (NULL or "" = all): two event
+/* Restrict the timing to launches whose kernel-family name starts with one of the comma-separated prefixes in
+ * `name_prefix` (NULL or "" = all): two event
  * records per launch cost ~2 us of host time each, 0.18 ms per forward when all ~45 launches are timed. */
 int         msnet_prof_select(const char* name_prefix);
 long        msnet_prof_collect(char* buf_host, size_t buf_bytes);
+
+/* Measured-attainable peaks of this device for bench.py's roofline denominators; diagnostics, not on
+ * the product path.  msnet_peak_copy: one float4 copy of `bytes` bytes (2 * bytes of HBM traffic).  msnet_peak_mfma_f16:
+ * a full-chip grid of waves issuing `iters` x 8 v_mfma_f32_32x32x16_f16 on registers; returns the FLOPs of the call
+ * (0 on error); `scratch` is any device buffer of >= 1 MiB.  Time both with events on `stream`. */
+int    msnet_peak_copy(const void* src, void* dst, size_t bytes, msnet_stream_t stream);
+double msnet_peak_mfma_f16(void* scratch, int iters, msnet_stream_t stream);
 
 /* ---- matchers: replaces src/cpp/matchers/matchers.cpp:565-580 (libmatchers) ----------------- */
 /* census(left,right,ndisp,wsize) matchers.cpp:232-353.  l,r: u8[H][W]; out: f32[H][W][ndisp];

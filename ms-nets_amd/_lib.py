@@ -25,6 +25,8 @@ SIGNATURES = {
     "msnet_prof_enable": (c_int, [c_int]),
     "msnet_prof_select": (c_int, [c_char_p]),
     "msnet_prof_collect": (c_long, [c_char_p, c_size_t]),
+    "msnet_peak_copy": (c_int, [P, P, c_size_t, P]),
+    "msnet_peak_mfma_f16": (ctypes.c_double, [P, c_int, P]),
     "msnet_census": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "msnet_census_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "msnet_ncc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),

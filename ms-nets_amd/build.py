@@ -16,10 +16,13 @@ ARCH = "gfx950"
 SOURCES = [
     ("api.cpp", []),
     ("pack.hip", []),
+    ("peaks.hip", []),
     ("conv3d.hip", []),
     ("conv3d_f16s.hip", []),
     ("tail.hip", []),
     ("volume.hip", ["-ffp-contract=off"]),
+    # -fno-slp-vectorize: hipcc otherwise packs the ZSAD add chains into v_pk_add_f32 + v_and (no |x| modifier) + v_mov
+    ("volume_fused.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),
 ]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=" + ARCH, "-Wall", "-Wno-unused-function",
           "-fno-gpu-rdc"]

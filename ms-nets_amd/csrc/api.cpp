@@ -35,11 +35,23 @@ struct Rec {
 static std::mutex g_mu;
 static std::vector<Rec*> g_recs;
 static volatile int g_prof = 0;
-static char g_prof_prefix[64] = "";      // only launches whose name starts with this are timed ("" = all)
+static char g_prof_prefix[256] = "";     // comma-separated name prefixes; only matching launches are timed ("" = all)
+
+static bool prof_selected(const char* n) {
+    if (!g_prof_prefix[0]) return true;
+    for (const char* p = g_prof_prefix; *p;) {
+        const char* e = strchr(p, ',');
+        const size_t len = e ? (size_t)(e - p) : strlen(p);
+        if (len && strncmp(n, p, len) == 0) return true;
+        if (!e) break;
+        p = e + 1;
+    }
+    return false;
+}
 
 LaunchScope::LaunchScope(const char* n, hipStream_t s, double flops, double bytes) : name(n), stream(s), rec(nullptr) {
     if (!g_prof) return;
-    if (g_prof_prefix[0] && strncmp(n, g_prof_prefix, strlen(g_prof_prefix)) != 0) return;
+    if (!prof_selected(n)) return;
     Rec* r = new Rec{n, nullptr, nullptr, flops, bytes};
     if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return; }
     (void)hipEventRecord(r->a, s);

@@ -1323,15 +1323,20 @@ __global__ __launch_bounds__(256) void conv3d_direct_f16s_kernel(ConvArgs a, int
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, hh = lane >> 5;
     const int nblk = a.Co / 32;
-    const long total = (long)a.N * a.OD * a.OH * a.OW;
-    const long mblk = blockIdx.x / nblk;
+    // M-blocks never straddle two samples (blocks per sample = ceil(voxels / 32)), so a sample's result does not depend on
+    // its position in the batch: the same taps go to the same waves and the partial sums meet in the same order.
+    const long svox = (long)a.OD * a.OH * a.OW;           // output voxels per sample
+    const long bps = (svox + 31) / 32;
+    const long mblk_all = blockIdx.x / nblk;
     const int nb = blockIdx.x % nblk;
+    const int n = (int)(mblk_all / bps);
+    const long mblk = mblk_all % bps;
     long v = mblk * 32 + r;
-    const bool vok = v < total;
-    if (!vok) v = total - 1;
-    const int ow = (int)(v % a.OW), oh = (int)((v / a.OW) % a.OH), od = (int)((v / ((long)a.OW * a.OH)) % a.OD);
-    const int n = (int)(v / ((long)a.OW * a.OH * a.OD));
-    const auto rs_x = make_rsrc(a.x, (size_t)a.N * a.D * a.H * a.W * a.Ci * 4);
+    const bool vok = v < svox;
+    if (!vok) v = svox - 1;
+    const int ow = (int)(v % a.OW), oh = (int)((v / a.OW) % a.OH), od = (int)(v / ((long)a.OW * a.OH));
+    const size_t ibytes = (size_t)a.D * a.H * a.W * a.Ci * 4;                   // descriptors cover ONE sample
+    const auto rs_x = make_rsrc(a.x + (size_t)n * (ibytes / 4), ibytes);
     const u32x4* wq = reinterpret_cast<const u32x4*>(a.wpk);
     const int nchunks = KK / KS;
 
@@ -1361,7 +1366,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_f16s_kernel(ConvArgs a, int
         ok = ok && (unsigned)id < (unsigned)a.D && (unsigned)ih < (unsigned)a.H && (unsigned)iw < (unsigned)a.W;
         if (__builtin_amdgcn_ballot_w64(ok) == 0) continue;
         if ((nvalid++ & 3) != wave) continue;           // the block's usable taps are dealt round-robin to its four waves
-        const unsigned voff = ok ? (unsigned)(((((size_t)n * a.D + id) * a.H + ih) * a.W + iw) * a.Ci) * 4u + 32u * hh : 0xffffffffu;
+        const unsigned voff = ok ? (unsigned)((((size_t)id * a.H + ih) * a.W + iw) * a.Ci) * 4u + 32u * hh : 0xffffffffu;
         f32x4 x0[KK], x1[KK];
         u32x4 wb[KK][2];
 #pragma unroll
@@ -1400,9 +1405,9 @@ __global__ __launch_bounds__(256) void conv3d_direct_f16s_kernel(ConvArgs a, int
 #pragma unroll
     for (int e = 0; e < 16; ++e) sum[e] += red[0][e][lane] + red[1][e][lane] + red[2][e][lane];
     // epilogue: lane = channel nb*32 + r, register e = voxel mblk*32 + (e&3) + 8*(e>>2) + 4*hh of the flattened output
-    const size_t obytes = (size_t)total * a.Co * 4;
-    const auto rs_y = make_rsrc(a.y, obytes);
-    const auto rs_res = make_rsrc(a.res, a.res ? obytes : 0);
+    const size_t obytes = (size_t)svox * a.Co * 4;         // one sample; the buffer bound drops the tail of its last block
+    const auto rs_y = make_rsrc(a.y + (size_t)n * (obytes / 4), obytes);
+    const auto rs_res = make_rsrc(a.res ? a.res + (size_t)n * (obytes / 4) : nullptr, a.res ? obytes : 0);
     const int co = nb * 32 + r;
     const float sc = a.scale ? a.scale[co] : 1.f;
     const float sh = a.shift ? a.shift[co] : 0.f;
@@ -1415,8 +1420,10 @@ __global__ __launch_bounds__(256) void conv3d_direct_f16s_kernel(ConvArgs a, int
 // true if the direct kernel ran (small layer), false if the caller should use a tiled kernel, negative never
 template <bool TR>
 static int launch_direct_f16s(const char* name, ConvArgs a, int stride, int KS, int NBG, hipStream_t s) {
-    const size_t total = (size_t)a.N * a.OD * a.OH * a.OW;
-    const size_t nblocks = ((total + 31) / 32) * (a.Co / 32);
+    const size_t svox = (size_t)a.OD * a.OH * a.OW;
+    const size_t total = (size_t)a.N * svox;
+    const size_t nblocks = (size_t)a.N * ((svox + 31) / 32) * (a.Co / 32);
+    if (nblocks > 0x7fffffffu) return fail("%s: too many blocks", name);
     const int KK = a.Ci / 16;
     const double vox = TR ? (double)a.N * a.D * a.H * a.W : (double)total;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
@@ -1432,7 +1439,7 @@ static int launch_direct_f16s(const char* name, ConvArgs a, int stride, int KS, 
 static bool direct_shape_ok(const ConvArgs& a) {
     const int KK = a.Ci / 16;
     if (a.Ci % 16 || !(KK == 2 || KK == 4 || KK == 8) || a.Co % 32) return false;
-    return (size_t)a.N * a.D * a.H * a.W * a.Ci * 4 <= 0xfffffff0u && (size_t)a.N * a.OD * a.OH * a.OW * a.Co * 4 <= 0xfffffff0u;
+    return (size_t)a.D * a.H * a.W * a.Ci * 4 <= 0xfffffff0u && (size_t)a.OD * a.OH * a.OW * a.Co * 4 <= 0xfffffff0u;     // per sample
 }
 // a layer is "small" when the tiled kernel would have work for fewer than a quarter of the CUs (measured: at 108 tiles the
 // tiled kernel still wins, 49 vs 61 us; at 30-54 tiles the direct one does, 37 vs 75 and 23 vs 40 us)
@@ -1553,8 +1560,9 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
     a.OD = (D - 1) / stride + 1; a.OH = (H - 1) / stride + 1; a.OW = (W - 1) / stride + 1;
     hipStream_t s = (hipStream_t)stream;
     {   // small layers: one workgroup per 32x32 output block instead of a handful of persistent tile walkers
-        const size_t items = stride == 2 ? (size_t)N * cdiv(a.OD, 2) * cdiv(a.OH, 2) * cdiv(a.OW, 32) * (Co / 64)
-                                         : (size_t)N * cdiv(a.OD, 2) * cdiv(a.OH, 4) * cdiv(a.OW, 32) * (Co == 32 ? 1 : Co / 64);
+        // items of ONE sample: the choice (and with it the summation order) must not depend on the batch size
+        const size_t items = stride == 2 ? (size_t)cdiv(a.OD, 2) * cdiv(a.OH, 2) * cdiv(a.OW, 32) * (Co / 64)
+                                         : (size_t)cdiv(a.OD, 2) * cdiv(a.OH, 4) * cdiv(a.OW, 32) * (Co == 32 ? 1 : Co / 64);
         if (direct_eligible(a, items))
             return launch_direct_f16s<false>(stride == 2 ? "conv3d_s2_f16s" : (Co == 32 ? "conv3d_s1_f16s_co32" : "conv3d_s1_f16s_co64"),
                                              a, stride, stride == 2 ? 1 : 2, Co == 32 ? 1 : 2, s);
@@ -1607,7 +1615,7 @@ extern "C" int msnet_deconv3d_k3s2_f16s(const float* x, const void* wpk_f16s, co
     a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu;
     a.OD = 2 * D; a.OH = 2 * H; a.OW = 2 * W;
     const bool tiled_ok = Ci == 64 && (Co == 32 || Co == 64);
-    const size_t items = (size_t)N * cdiv(D, 2) * cdiv(H, 4) * cdiv(W, 32) * (Co / 32);
+    const size_t items = (size_t)cdiv(D, 2) * cdiv(H, 4) * cdiv(W, 32) * (Co / 32);      // per sample (batch-invariant choice)
     if (!tiled_ok || direct_eligible(a, items)) {
         if (!direct_shape_ok(a)) return fail("msnet_deconv3d_k3s2_f16s: Ci=%d Co=%d at this size needs the fp32 kernel", Ci, Co);
         return launch_direct_f16s<true>("deconv3d_f16s", a, 2, Ci / 16, 1, (hipStream_t)stream);

@@ -1,0 +1,62 @@
+// Measured-attainable peaks of the device the library runs on ("confirm on the box ... a STREAM-like
+// copy and an MFMA micro-bench and use measured-attainable peaks alongside vendor peaks").  Diagnostics for bench.py's roofline
+// denominators; nothing on the product path calls these.
+//   msnet_peak_copy      : float4 copy src -> dst (bytes read + bytes written per call = 2 * bytes)
+//   msnet_peak_mfma_f16  : every wave of a full-chip grid issues `iters` x 8 independent v_mfma_f32_32x32x16_f16 on register
+//                          operands (no memory traffic): the dense fp16 MFMA rate at the clock the chip sustains under that load
+#include "common.h"
+
+namespace msnet {
+
+typedef _Float16 half8_p __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void peak_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n4) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void peak_mfma_f16_kernel(float* __restrict__ out, int iters, float seed) {
+    const int lane = threadIdx.x & 63;
+    half8_p a, b;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                          // non-trivial operands: zeros would let the chip clock higher
+        a[k] = (_Float16)(seed * (float)((lane * 7 + k * 3) % 17 - 8) * 0.0625f);
+        b[k] = (_Float16)(seed * (float)((lane * 5 + k * 11) % 13 - 6) * 0.125f);
+    }
+    f32x16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[j][e];
+    if (s == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;     // keeps the MFMAs live, practically never stores
+}
+
+}  // namespace msnet
+
+using namespace msnet;
+
+extern "C" int msnet_peak_copy(const void* src, void* dst, size_t bytes, msnet_stream_t stream) {
+    if (!src || !dst || bytes < 16) return fail("msnet_peak_copy: bad arguments");
+    hipLaunchKernelGGL(peak_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, bytes / 16);
+    return check_launch("msnet_peak_copy");
+}
+
+/* returns the FLOPs one call executes (0 on error): waves * iters * 8 MFMAs * 2*32*32*16 */
+extern "C" double msnet_peak_mfma_f16(void* scratch, int iters, msnet_stream_t stream) {
+    if (!scratch || iters <= 0) { fail("msnet_peak_mfma_f16: bad arguments"); return 0.0; }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int blocks = cus * 2;                            // 8 waves per CU = 2 per SIMD
+    hipLaunchKernelGGL(peak_mfma_f16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)scratch, iters, 1.0f);
+    if (check_launch("msnet_peak_mfma_f16")) return 0.0;
+    return (double)blocks * 4.0 * iters * 8.0 * 2.0 * 32 * 32 * 16;
+}

@@ -582,7 +582,7 @@ __global__ void softargmin_kernel(const float* __restrict__ logits, float* __res
 }
 
 // F.interpolate(cost[N][1][d][h][w], [D][H][W], 'trilinear', align_corners=True) + softmax(D) + sum d*p.
-// Source coordinate = dst * (in-1)/(out-1) (float), i1 = i0 + (i0 < in-1), as ATen's upsample_trilinear3d.
+// Source coordinate = fl(dst * fl((in-1)/(out-1))) (float), i1 = i0 + (i0 < in-1), lambda1 = src - i0, as ATen's upsample_trilinear3d.
 __global__ void trilinear_softargmin_kernel(const float* __restrict__ cost, float* __restrict__ disp, int N, int d,
                                             int h, int w, int D, int H, int W) {
     const float sd = (D > 1) ? (float)(d - 1) / (float)(D - 1) : 0.f;
@@ -591,7 +591,11 @@ __global__ void trilinear_softargmin_kernel(const float* __restrict__ cost, floa
     const size_t total = (size_t)N * H * W;
     for (size_t o = (size_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (size_t)gridDim.x * blockDim.x) {
         const int X = o % W, Y = (o / W) % H, n = (int)(o / ((size_t)W * H));
-        const float fy = sh * Y, fx = sw * X;
+        // The product is ROUNDED before the floor and the subtraction, as in ATen (area_pixel_compute_source_index);
+        // contracted into fma(s, X, -x0) the weights differ from torch's by up to half an ulp of the source index (1.5e-5 at
+        // W' = 240), which a broad D = 192 softmax turns into 1e-2 of disparity.
+        float fy = sh * (float)Y, fx = sw * (float)X;
+        asm volatile("" : "+v"(fy), "+v"(fx));        // the rounded products, not fma operands
         const int y0 = (int)fy, x0 = (int)fx;
         const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
         const float ly1 = fy - y0, lx1 = fx - x0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
@@ -604,7 +608,8 @@ __global__ void trilinear_softargmin_kernel(const float* __restrict__ cost, floa
         int zc = 0;
         float v0 = plane(0), v1 = plane(d > 1 ? 1 : 0);
         for (int Z = 0; Z < D; ++Z) {
-            const float fz = sd * Z;
+            float fz = sd * (float)Z;
+            asm volatile("" : "+v"(fz));
             const int z0 = (int)fz;
             const float lz1 = fz - z0, lz0 = 1.f - lz1;
             while (zc < z0) {           // advance the two cached source slices

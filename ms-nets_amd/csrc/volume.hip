@@ -9,6 +9,8 @@
 // ORDER is part of the reference's result, so nothing here may be fused into an FMA or
 // re-associated.  Integer paths (census, sobel, the NCC window sums) are exact by construction.
 // Entries the reference never writes keep its fill value RAND_MAX -> 2^31 (kSentinel).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace msnet {
@@ -798,6 +800,12 @@ static int sadsob_impl(const float* sl, const float* sr, float* out, float* ws, 
     return check_launch("sadsob");
 }
 
+// fast path for the reference's default windows (volume_fused.hip)
+bool volume_fast_supported(const msnet_volume_params& p, int Hb, int Wb, int nd);
+size_t volume_fast_workspace_bytes(int Hb, int Wb, int nd);
+int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int nd, const msnet_volume_params& p, void* workspace,
+                       float* out, hipStream_t s);
+
 }  // namespace msnet
 
 using namespace msnet;
@@ -920,7 +928,8 @@ extern "C" size_t msnet_build_volume_workspace_bytes(int Hb, int Wb, int ndisp) 
     const size_t img = (size_t)Hb * Wb;
     const size_t bytes = ((size_t)ndisp * (Hb + 1) * (Wb + 1) + 4 * img) * sizeof(float) + 4 * img * sizeof(double) +
                          16 * img * sizeof(uint32_t) + 64;
-    return (bytes + 255) & ~(size_t)255;
+    const size_t fast = volume_fast_workspace_bytes(Hb, Wb, ndisp);
+    return ((bytes > fast ? bytes : fast) + 255) & ~(size_t)255;
 }
 
 extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int ndisp,
@@ -937,6 +946,10 @@ extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, in
     if (int e = check_img("msnet_build_volume", l, r, out, Hb, Wb, ndisp, p.sadw)) return e;
     if (int e = check_img("msnet_build_volume", l, r, out, Hb, Wb, ndisp, p.sobelw)) return e;
     hipStream_t s = (hipStream_t)stream;
+    // MSNET_VOLUME_GENERIC=1 forces the run-time-window kernels below (A/B tests of the two paths)
+    const char* generic = getenv("MSNET_VOLUME_GENERIC");
+    if (!(generic && generic[0] == '1') && volume_fast_supported(p, Hb, Wb, ndisp))
+        return volume_fast_launch(l, r, Hb, Wb, ndisp, p, workspace, out, s);
     const size_t img = (size_t)Hb * Wb;
     float* integ = (float*)workspace;
     float* sobl = integ + (size_t)ndisp * (Hb + 1) * (Wb + 1);
@@ -956,19 +969,19 @@ extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, in
     a.censw = p.censw; a.nccw = p.nccw; a.sadw = p.sadw; a.sobelw = p.sobelw; a.nwords = nwords;
 
     {
-        LaunchScope ls("volume_prep", s, 0, 2.0 * img * (1 + 4.0 * nwords) + 48.0 * img);
+        LaunchScope ls("vol_prep", s, 0, 2.0 * img * (1 + 4.0 * nwords) + 48.0 * img);
         hipLaunchKernelGGL(volume_prep_kernel, dim3(cdiv(Wb, 64), Hb, 5), dim3(64), 0, s, a, sobl, sobr);
     }
     {
-        LaunchScope ls("sadsob_vertical", s, 0, 4.0 * ndisp * (double)(Hb + 1) * (Wb + 1));
+        LaunchScope ls("vol_sadsob_v", s, 0, 4.0 * ndisp * (double)(Hb + 1) * (Wb + 1));
         hipLaunchKernelGGL(sadsob_vertical_kernel, dim3(cdiv(Wb + 1, 64), ndisp), dim3(64), 0, s, sobl, sobr, integ, Hb, Wb, ndisp);
     }
     {
-        LaunchScope ls("sadsob_horizontal", s, 0, 8.0 * ndisp * (double)(Hb + 1) * (Wb + 1));
+        LaunchScope ls("vol_sadsob_h", s, 0, 8.0 * ndisp * (double)(Hb + 1) * (Wb + 1));
         hipLaunchKernelGGL(sadsob_horizontal_kernel, dim3(cdiv(Hb + 1, 64), ndisp), dim3(64), 0, s, integ, Hb, Wb, ndisp);
     }
     {
-        LaunchScope ls("features", s, 0, 4.0 * 8.0 * ndisp * (double)Hc * Wc);
+        LaunchScope ls("vol_features", s, 0, 4.0 * 8.0 * ndisp * (double)Hc * Wc);
         const dim3 gf(cdiv(Wc, 64), cdiv(Hc, 4), 4);
         if (p.censw == 11 && p.nccw == 3 && p.sobelw == 5 && p.sadw == 5)
             hipLaunchKernelGGL((features_all_kernel<11, 3, 5, 5>), gf, dim3(256), 0, s, a);

@@ -1,0 +1,585 @@
+// Fast path of msnet_build_volume for the reference's own parameters (windows 11 / 3 / 5 / 5, cbmv_generator.py:434-462):
+// three launches from the two bordered uint8 images to the [8, D', H', W'] float32 volume.
+//
+//   vprep_kernel       per-pixel tables from LDS-staged image tiles: census bit images, NCC window sums + 1/sqrt terms,
+//                      ZSAD window means, Sobel images                                  (matchers.cpp:268-300,71-147,472-485,515-554)
+//   sadsob_band_kernel the float32 integral image of |SL - SR_shift| NEVER goes to HBM: one workgroup owns one
+//                      disparity and one band of rows, runs the reference's sequential vertical pass (one thread per
+//                      column, from row 0: the rows above the band are re-accumulated, they cost two cached loads each),
+//                      keeps the band in LDS, runs the sequential horizontal pass (one lane per row) and evaluates the
+//                      5x5 boxes.  Same additions in the same order as matchers.cpp:388-423, so bit-identical.
+//   features_kernel    one thread = one cropped pixel of one matcher; the D' raw costs stay in REGISTERS (the d loop is
+//                      fully unrolled, right-image data comes from LDS strips), so each output element is written once
+//                      and expf is evaluated once per element:
+//                        pass 1  raw cost c_d for every d -> normalised cost channel (cbmv_generator.py:283-287), min
+//                        pass 2  e_d = expf(-(c_d - m)^2 / sigma), den += e_d in d order (featextract.cpp:444-447)
+//                        pass 3  likelihood channel e_d / den (featextract.cpp:452-458)
+//
+// HBM traffic per map: the 8 output channels (401 MB at 960x544, D=192) + the parked Sobel-SAD raw costs (50 MB written,
+// 50 MB read back) + the small tables.  Built with -ffp-contract=off like volume.hip: float32 operation order is part
+// of the reference's result.
+#include "common.h"
+
+namespace msnet {
+
+constexpr int kCW = 11, kNW = 3, kSW = 5, kZW = 5;      // census / NCC / Sobel-SAD / ZSAD windows of the fast path
+
+struct FastArgs {
+    const uint8_t* l; const uint8_t* r;
+    uint4* lb; uint4* rb;               // census bit images [Hb*Wb], 121 bits in 4 words (order private to this file)
+    double2* ncl; double2* ncr;         // NCC tables {window sum A, 1/sqrt term C} per pixel
+    float* ml; float* mr;               // ZSAD window means
+    float* sobl; float* sobr;           // Sobel images
+    float* out;
+    float sigma[4], rsigma[4];          // rsigma = RN(1 / sigma), computed on the host
+    int Hb, Wb, nd, bh, bw, Hc, Wc;
+};
+
+// ------------------------------------------------------------------------------------------------ prep
+// 64 x 4 pixel tiles, blockIdx.z: 0 census L, 1 census R, 2 tables (NCC, ZSAD means, Sobel) of both images.
+__global__ __launch_bounds__(256) void vprep_kernel(FastArgs a) {
+    __shared__ uint8_t tile[2][14][80];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 4;
+    const int x = x0 + tx, y = y0 + ty;
+    const int W = a.Wb, H = a.Hb;
+    if (blockIdx.z < 2) {
+        const uint8_t* img = blockIdx.z == 0 ? a.l : a.r;
+        for (int k = threadIdx.x; k < 14 * 74; k += 256) {
+            const int r = k / 74, c = k % 74;
+            const int gy = y0 - 5 + r, gx = x0 - 5 + c;
+            tile[0][r][c] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? img[gy * W + gx] : 0;
+        }
+        __syncthreads();
+        if (x >= W || y >= H) return;
+        uint32_t wd[4] = {0u, 0u, 0u, 0u};
+        const int i = y - 5, j = x - 5;
+        if (i >= 0 && j >= 0 && i < H - kCW && j < W - kCW) {     // matchers.cpp:283 (i < H - wsize, not <=)
+            const int c = tile[0][ty + 5][tx + 5];
+#pragma unroll
+            for (int wh = 0; wh < kCW; ++wh)
+#pragma unroll
+                for (int ww = 0; ww < kCW; ++ww) {
+                    const int b = wh * kCW + ww;
+                    const uint32_t lt = (uint32_t)(c - (int)tile[0][ty + wh][tx + ww]) >> 31;   // center < pixel
+                    wd[b >> 5] = (wd[b >> 5] << 1) | lt;
+                }
+        }
+        (blockIdx.z == 0 ? a.lb : a.rb)[(size_t)y * W + x] = make_uint4(wd[0], wd[1], wd[2], wd[3]);
+        return;
+    }
+    for (int k = threadIdx.x; k < 2 * 8 * 68; k += 256) {
+        const int im = k / (8 * 68), q = k % (8 * 68), r = q / 68, c = q % 68;
+        const int gy = y0 - 2 + r, gx = x0 - 2 + c;
+        const uint8_t* img = im == 0 ? a.l : a.r;
+        tile[im][r][c] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? img[gy * W + gx] : 0;
+    }
+    __syncthreads();
+    if (x >= W || y >= H) return;
+    const size_t p = (size_t)y * W + x;
+    {   // NCC 3x3 (window top-left i = y-1, j = x-1)
+        const int i = y - 1, j = x - 1;
+        double2 tl = make_double2(0.0, 0.0), tr = make_double2(0.0, 0.0);
+        if (i >= 0 && j >= 0 && i < H - kNW && j < W - kNW) {
+            unsigned sl = 0, sr = 0, ql = 0, qr = 0;
+#pragma unroll
+            for (int wh = 0; wh < kNW; ++wh)
+#pragma unroll
+                for (int ww = 0; ww < kNW; ++ww) {
+                    const unsigned u = tile[0][ty + 1 + wh][tx + 1 + ww], v = tile[1][ty + 1 + wh][tx + 1 + ww];
+                    sl += u; sr += v; ql += u * u; qr += v * v;
+                }
+            const unsigned long long sq = (unsigned long long)(kNW * kNW);
+            tl.x = (double)sl; tr.x = (double)sr;
+            tl.y = 1.0 / sqrt((double)(sq * ql) - (double)sl * (double)sl);
+            tr.y = 1.0 / sqrt((double)(sq * qr) - (double)sr * (double)sr);
+        }
+        a.ncl[p] = tl; a.ncr[p] = tr;
+    }
+    {   // ZSAD means 5x5: sequential float sum of <= 25 bytes is exact, then one division
+        const int i = y - 2, j = x - 2;
+        float ml = 0.f, mr = 0.f;
+        if (i >= 0 && j >= 0 && i < H - kZW && j < W - kZW) {
+            unsigned sl = 0, sr = 0;
+#pragma unroll
+            for (int wh = 0; wh < kZW; ++wh)
+#pragma unroll
+                for (int ww = 0; ww < kZW; ++ww) { sl += tile[0][ty + wh][tx + ww]; sr += tile[1][ty + wh][tx + ww]; }
+            ml = (float)sl / (float)(kZW * kZW);
+            mr = (float)sr / (float)(kZW * kZW);
+        }
+        a.ml[p] = ml; a.mr[p] = mr;
+    }
+    {   // Sobel, written at (i+1, j+1) for i < H-3, j < W-3
+        const int i = y - 1, j = x - 1;
+        float vl = 0.f, vr = 0.f;
+        if (i >= 0 && j >= 0 && i < H - 3 && j < W - 3) {
+#pragma unroll
+            for (int im = 0; im < 2; ++im) {
+                const int s = -(int)tile[im][ty + 1][tx + 1] + (int)tile[im][ty + 1][tx + 3] - 2 * (int)tile[im][ty + 2][tx + 1] +
+                              2 * (int)tile[im][ty + 2][tx + 3] - (int)tile[im][ty + 3][tx + 1] + (int)tile[im][ty + 3][tx + 3];
+                (im == 0 ? vl : vr) = (float)s;
+            }
+        }
+        a.sobl[p] = vl; a.sobr[p] = vr;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ Sobel-SAD
+// The reference's vertical pass is one sequential float32 chain per (disparity, column) over all rows.  It is cut into
+// bands of R cropped rows by CHECKPOINTS: sadsob_ckpt_kernel walks every chain once (two cached loads per element, 16 rows
+// of loads in flight) and keeps only the running sum in front of each band; sadsob_band_kernel resumes from there.
+//   ck[(d * nbands + band) * LS + c] = S_vertical[i_lo(band) - 1][c],   i_lo(band) = band * R + border_h - 2
+template <int R>
+__global__ __launch_bounds__(256) void sadsob_ckpt_kernel(FastArgs a, float* __restrict__ ck, int LS, int nbands, int rows) {
+    // Phase 1: all 256 threads fetch |SL - SR_shift| of 64 columns x `rows` image rows into LDS (every load independent, so
+    // the whole strip is in flight at once); phase 2: one thread per column walks its chain out of LDS.
+    extern __shared__ __attribute__((aligned(16))) float A[];     // [rows][64]
+    const int c0 = blockIdx.x * 64;                        // first integral column of the strip
+    const int d = blockIdx.y;
+    const int W = a.Wb;
+    for (int k = threadIdx.x; k < rows * 64; k += 256) {
+        const int i = k >> 6, c = c0 + (k & 63), j = c - 1;
+        float v = 0.f;
+        if (c <= W && j >= d) v = fabsf(a.sobl[i * W + j] - a.sobr[i * W + j - d]);
+        A[k] = v;
+    }
+    __syncthreads();
+    const int c = c0 + threadIdx.x;
+    if (threadIdx.x >= 64 || c >= LS) return;
+    float* o = ck + (size_t)d * nbands * LS + c;
+    float run = 0.f;                                       // columns with j < d only ever add +0
+    int i = 0;
+    for (int b = 0; b < nbands; ++b) {
+        const int target = b * R + a.bh - kSW / 2 - 1;     // image rows 0 .. target-1 make integral row i_lo(b) - 1
+        for (; i < target; ++i) run = A[i * 64 + threadIdx.x] + run;
+        o[(size_t)b * LS] = run;
+    }
+}
+
+// Workgroup = (disparity d, band of R cropped rows).  LDS holds the R + 5 integral rows the band's boxes touch, row
+// stride LS with LS % 8 == 4 so that `lane = row` ds_read_b128 / ds_write_b128 accesses are conflict-free: vertical pass
+// (thread = column, resumed from the checkpoint), horizontal pass (lane = row, strictly sequential from column d+1,
+// matchers.cpp:406-411), then the 5x5 boxes.  `park` receives the raw box costs [nd][Hc][Wc] (kSentinel where the
+// reference leaves RAND_MAX).  The float32 integral image itself never goes to HBM.
+template <int R, int NT>
+__global__ __launch_bounds__(NT) void sadsob_band_kernel(FastArgs a, const float* __restrict__ ck, float* __restrict__ park, int LS,
+                                                         int nbands) {
+    extern __shared__ __attribute__((aligned(16))) float S[];     // [R + 5][LS]
+    constexpr int NR = R + kSW;
+    const int d = blockIdx.x / nbands;
+    const int band = blockIdx.x % nbands;
+    const int yc0 = band * R;                              // first cropped row of the band
+    const int W = a.Wb, H = a.Hb;
+    const int i_lo = yc0 + a.bh - kSW / 2;                 // first integral row kept  (= window top of the band's first row)
+    const int i_hi = min(i_lo + NR - 1, H);                // last integral row kept
+    const int tid = threadIdx.x;
+
+    // vertical pass: S[i][c] = S[i-1][c] + |SL[i-1][c-1] - SR[i-1][c-1-d]|, image rows i_lo-1 .. i_hi-1
+    for (int c = tid; c < LS; c += NT) {
+        const int j = c - 1;
+        if (c > W || j < d) {
+            for (int rr = 0; rr <= i_hi - i_lo; ++rr) S[rr * LS + c] = 0.f;
+            continue;
+        }
+        const float* pl = a.sobl + j;
+        const float* pr = a.sobr + j - d;
+        float run = ck[((size_t)d * nbands + band) * LS + c];
+        for (int i = i_lo - 1; i < i_hi; i += 16) {
+            float v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const int row = min(i + k, H - 1); v[k] = fabsf(pl[row * W] - pr[row * W]); }
+#pragma unroll
+            for (int k = 0; k < 16; ++k)
+                if (i + k < i_hi) { run = v[k] + run; S[(i + k + 1 - i_lo) * LS + c] = run; }
+        }
+    }
+    __syncthreads();
+
+    // horizontal pass
+    const int c_last = min(W, W - a.bw + kSW);             // last integral column any cropped box reads
+    if (tid < 64 && tid <= i_hi - i_lo) {
+        float* row = S + tid * LS;
+        float run = 0.f;
+        int c = (d + 1) & ~3;                              // columns <= d hold zeros: adding them keeps run == 0
+        auto rd = [&](int cc) { return *reinterpret_cast<const f32x4*>(row + min(cc, LS - 4)); };
+        f32x4 v0 = rd(c), v1 = rd(c + 4), v2 = rd(c + 8);  // three reads ahead of the add chain (LDS latency)
+        for (; c <= c_last; c += 4) {
+            const f32x4 nx = rd(c + 12);
+            run = v0[0] + run; v0[0] = run;
+            run = v0[1] + run; v0[1] = run;
+            run = v0[2] + run; v0[2] = run;
+            run = v0[3] + run; v0[3] = run;
+            *reinterpret_cast<f32x4*>(row + c) = v0;
+            v0 = v1; v1 = v2; v2 = nx;
+        }
+    }
+    __syncthreads();
+
+    // boxes: cost(y, x) = S[b][r] - S[b][l] - S[t][r] + S[t][l], window top-left (y-2, x-2)
+    const size_t plane = (size_t)a.Hc * a.Wc;
+    const int rows = min(R, a.Hc - yc0);
+    int rr = 0, x = tid;
+    while (x >= a.Wc) { x -= a.Wc; ++rr; }
+    while (rr < rows) {
+        const float* t = S + rr * LS;
+        const float* b = t + kSW * LS;
+        const int j = x + a.bw - kSW / 2;
+        float c = kSentinel;
+        if (j >= d) {
+            float q = b[j + kSW] - b[j];
+            q = q - t[j + kSW];
+            q = q + t[j];
+            c = q;
+        }
+        park[(size_t)d * plane + (size_t)(yc0 + rr) * a.Wc + x] = c;
+        x += NT;
+        while (x >= a.Wc) { x -= a.Wc; ++rr; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ features
+// RN(a / b) from rb = RN(1 / b) in three operations (Markstein): q = RN(a * rb) is within one ulp of a / b, the residual
+// r = a - q * b is then exact in one fma, and RN(q + r * rb) is the correctly rounded quotient -- the same bits as the IEEE
+// division the reference performs (checked exhaustively for the census costs in tests/test_oracle_matchers.py and bit for
+// bit against the dividing kernels of volume.hip in tests/test_gpu_volume.py), at a third of its instructions.
+__device__ __forceinline__ float div_rn(float a, float b, float rb) {
+    const float q = a * rb;
+    const float r = __builtin_fmaf(-q, b, a);
+    return __builtin_fmaf(r, rb, q);
+}
+
+__device__ __forceinline__ float norm_cost(int M, float c) {
+    if (M == 0) return div_rn(fminf(fmaxf(c, 0.f), 120.f), 120.f, 1.f / 120.f);    // cbmv_generator.py:283
+    if (M == 1) { float t = fminf(fmaxf(c, -1.f), 1.f); t = 1.f + t; return t * 0.5f; }   // :285 (x / 2 is exact)
+    return fminf(fmaxf(c, 0.f), 8192.f) * (1.f / 8192.f);                           // :286-287 (x / 2^13 is exact)
+}
+
+__device__ __forceinline__ float aml_e(float c, float m, float sigma, float rsigma) {
+    const float num = c - m;
+    float q = num * num;
+    q = div_rn(q, sigma, rsigma);
+    return expf(-q);
+}
+
+// M: 0 census, 1 NCC, 2 Sobel-SAD (raw costs parked in its likelihood channel by sadsob_band_kernel), 3 ZSAD.
+// ND: compile-time bound on the disparities (register array); nd <= ND, nd % 8 == 0.
+template <int M, int ND>
+__device__ __forceinline__ void features_px(const FastArgs& a, unsigned char* smem) {
+    constexpr int SW_ = 64 + ND - 1;                       // strip columns: right-image column x - d, d = 0..ND-1
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int xc0 = blockIdx.x * 64, yc0 = blockIdx.y * 4;
+    const int xb0 = xc0 + a.bw, yb0 = yc0 + a.bh;
+    const int W = a.Wb, H = a.Hb, nd = a.nd;
+    const int tid = threadIdx.x;
+
+    // ---- stage the right-image data of this tile's rows in LDS: strip column s <-> image column xb0 - (ND-1) + s
+    if (M == 0) {
+        uint4* sb = reinterpret_cast<uint4*>(smem);        // [4][SW_]
+        for (int k = tid; k < 4 * SW_; k += 256) {
+            const int r = k / SW_, s = k % SW_;
+            const int gy = yb0 + r, gx = xb0 - (ND - 1) + s;
+            sb[k] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? a.rb[(size_t)gy * W + gx] : make_uint4(0, 0, 0, 0);
+        }
+    } else if (M == 1) {
+        double2* st = reinterpret_cast<double2*>(smem);    // [4][SW_] tables
+        uint8_t* si = smem + 4 * SW_ * 16;                  // [6][SW_ + 2] pixels, image column xb0 - 1 - (ND-1) + s
+        for (int k = tid; k < 4 * SW_; k += 256) {
+            const int r = k / SW_, s = k % SW_;
+            const int gy = yb0 + r, gx = xb0 - (ND - 1) + s;
+            st[k] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? a.ncr[(size_t)gy * W + gx] : make_double2(0.0, 0.0);
+        }
+        for (int k = tid; k < 6 * (SW_ + 2); k += 256) {
+            const int r = k / (SW_ + 2), s = k % (SW_ + 2);
+            const int gy = yb0 - 1 + r, gx = xb0 - 1 - (ND - 1) + s;
+            si[k] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? a.r[gy * W + gx] : 0;
+        }
+    } else if (M == 3) {
+        float* sm = reinterpret_cast<float*>(smem);        // [4][SW_] means
+        float* si = sm + 4 * SW_;                           // [8][SW_ + 4] pixels as float, image column xb0 - 2 - (ND-1) + s
+        for (int k = tid; k < 4 * SW_; k += 256) {
+            const int r = k / SW_, s = k % SW_;
+            const int gy = yb0 + r, gx = xb0 - (ND - 1) + s;
+            sm[k] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? a.mr[(size_t)gy * W + gx] : 0.f;
+        }
+        for (int k = tid; k < 8 * (SW_ + 4); k += 256) {
+            const int r = k / (SW_ + 4), s = k % (SW_ + 4);
+            const int gy = yb0 - 2 + r, gx = xb0 - 2 - (ND - 1) + s;
+            si[k] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? (float)a.r[gy * W + gx] : 0.f;
+        }
+    }
+    if (M != 2) __syncthreads();
+
+    const int x = xc0 + tx, y = yc0 + ty;
+    if (x >= a.Wc || y >= a.Hc) return;
+    const int xb = x + a.bw, yb = y + a.bh;
+    const size_t plane = (size_t)a.Hc * a.Wc;
+    // One buffer descriptor per output channel: a store is {descriptor, per-lane byte offset of the pixel, SCALAR byte
+    // offset of the disparity plane} -- no per-store 64-bit address arithmetic on the vector unit.
+    const unsigned pix4 = (unsigned)(y * a.Wc + x) * 4u;
+    const unsigned plane4 = (unsigned)plane * 4u;
+    const unsigned chan_bytes = (unsigned)nd * plane4;     // <= 4 GB checked on the host
+    const __amdgpu_buffer_rsrc_t o_cost = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)M * nd * plane, 0, (int)chan_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t o_aml = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)(4 + M) * nd * plane, 0, (int)chan_bytes, 0x00020000);
+    const size_t pl = (size_t)yb * W + xb;
+
+    float c[ND];
+    float m = kSentinel;
+
+    // ---- pass 1: raw costs.  The border (>= 6) makes every window of a cropped pixel spatially valid, so only the
+    // disparity range is tested: census d <= xb - 5 (matchers.cpp:318), the others d <= window-left column.
+    if (M == 0) {
+        const uint4 lw = a.lb[pl];
+        const uint4* sb = reinterpret_cast<const uint4*>(smem) + ty * SW_ + tx + (ND - 1);
+        const int jmax = xb - kCW / 2;
+#pragma unroll
+        for (int d0 = 0; d0 < ND; d0 += 8) {
+            if (d0 < nd) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int d = d0 + u;
+                    const uint4 rw = sb[-d];
+                    const int cnt = __popc(lw.x ^ rw.x) + __popc(lw.y ^ rw.y) + __popc(lw.z ^ rw.z) + __popc(lw.w ^ rw.w);
+                    c[d] = (d <= jmax) ? (float)cnt : kSentinel;
+                }
+            }
+        }
+    } else if (M == 1) {
+        const double2 tl = a.ncl[pl];
+        const double Al = tl.x, Cl = tl.y;
+        const bool lfin = isfinite(Cl);
+        const double2* st = reinterpret_cast<const double2*>(smem) + ty * SW_ + tx + (ND - 1);
+        const uint8_t* si = smem + 4 * SW_ * 16 + ty * (SW_ + 2) + tx + (ND - 1);     // window top-left of d = 0
+        unsigned lv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) lv[k] = a.l[(yb - 1 + k / 3) * W + xb - 1 + k % 3];
+        const int jmax = xb - kNW / 2;
+        // sliding 3x3 window of the right image: the window of step d covers relative columns -d .. -d+2; relative
+        // column q lives in slot q mod 3, so a step loads only its new leftmost column (d is a constant after unrolling)
+        unsigned win[3][3];
+#pragma unroll
+        for (int wh = 0; wh < 3; ++wh) { win[wh][1] = si[wh * (SW_ + 2) + 1]; win[wh][2] = si[wh * (SW_ + 2) + 2]; }
+#pragma unroll
+        for (int d0 = 0; d0 < ND; d0 += 8) {
+            if (d0 < nd) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int d = d0 + u;
+                    const int s0 = (3 - d % 3) % 3;
+#pragma unroll
+                    for (int wh = 0; wh < 3; ++wh) win[wh][s0] = si[wh * (SW_ + 2) - d];
+                    unsigned LR = 0;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) LR += lv[k] * win[k / 3][(s0 + k % 3) % 3];
+                    const double2 tr = st[-d];
+                    float v;
+                    if (lfin && isfinite(tr.y)) {
+                        const double num = 9.0 * (double)LR - Al * tr.x;
+                        double t = -num;
+                        t = t * Cl;
+                        t = t * tr.y;
+                        v = (float)t;
+                    } else {
+                        v = 1.f;
+                    }
+                    c[d] = (d <= jmax) ? v : kSentinel;
+                }
+            }
+        }
+    } else if (M == 2) {
+#pragma unroll
+        for (int d0 = 0; d0 < ND; d0 += 8) {
+            if (d0 < nd) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    c[d0 + u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o_aml, pix4, (unsigned)(d0 + u) * plane4, 0));
+            }
+        }
+    } else {
+        const float mlv = a.ml[pl];
+        const float* sm = reinterpret_cast<const float*>(smem) + ty * SW_ + tx + (ND - 1);
+        const float* si = reinterpret_cast<const float*>(smem) + 4 * SW_ + ty * (SW_ + 4) + tx + (ND - 1);   // window top-left, d = 0
+        float lm[25];
+#pragma unroll
+        for (int k = 0; k < 25; ++k) lm[k] = (float)a.l[(yb - 2 + k / 5) * W + xb - 2 + k % 5] - mlv;
+        const int jmax = xb - kZW / 2;
+        // sliding 5x5 window of the right image: win[wh][(col) % 5]; step d needs columns -d .. -d+4 relative to si
+        float win[5][5];
+#pragma unroll
+        for (int wh = 0; wh < 5; ++wh)
+#pragma unroll
+            for (int q = 1; q < 5; ++q) win[wh][q] = si[wh * (SW_ + 4) + q];      // columns 1..4 of step d = 0
+#pragma unroll
+        for (int d0 = 0; d0 < ND; d0 += 8) {
+            if (d0 < nd) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int d = d0 + u;
+                    // new leftmost column (relative column -d) goes to slot (-d) mod 5 = (5 - d % 5) % 5
+                    const int s0 = (5 - d % 5) % 5;
+#pragma unroll
+                    for (int wh = 0; wh < 5; ++wh) win[wh][s0] = si[wh * (SW_ + 4) - d];
+                    const float mrv = sm[-d];
+                    float acc = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 25; ++k) {
+                        float t = lm[k] - win[k / 5][(s0 + k % 5) % 5];
+                        t = t + mrv;
+                        acc = acc + fabsf(t);
+                    }
+                    c[d] = (d <= jmax) ? acc : kSentinel;
+                    __builtin_amdgcn_sched_barrier(0);      // keeps the LDS reads of later steps from being hoisted (registers)
+                }
+            }
+        }
+    }
+
+    // normalised cost channel + min
+#pragma unroll
+    for (int d0 = 0; d0 < ND; d0 += 8) {
+        if (d0 < nd) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, norm_cost(M, c[d])), o_cost, pix4, (unsigned)d * plane4, 0);
+                if (c[d] < m) m = c[d];
+            }
+        }
+    }
+    // ---- pass 2: likelihood numerators, denominator accumulated in d order
+    const float sigma = a.sigma[M], rsigma = a.rsigma[M];
+    float den = 0.f;
+#pragma unroll
+    for (int d0 = 0; d0 < ND; d0 += 8) {
+        if (d0 < nd) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + u;
+                const float e = aml_e(c[d], m, sigma, rsigma);
+                den += e;
+                c[d] = e;
+            }
+        }
+    }
+    // ---- pass 3
+    const bool dead = (m == kSentinel);                    // all-sentinel row -> zeros (featextract.cpp:452)
+    const float rden = 1.f / den;                          // den >= 1: the minimum contributes expf(0)
+#pragma unroll
+    for (int d0 = 0; d0 < ND; d0 += 8) {
+        if (d0 < nd) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + u;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dead ? 0.f : div_rn(c[d], den, rden)), o_aml, pix4, (unsigned)d * plane4, 0);
+            }
+        }
+    }
+}
+
+template <int ND> constexpr size_t features_smem_bytes() {
+    constexpr size_t SW_ = 64 + ND - 1;
+    constexpr size_t m0 = 4 * SW_ * 16, m1 = 4 * SW_ * 16 + 6 * (SW_ + 2), m3 = 4 * SW_ * 4 + 8 * (SW_ + 4) * 4;
+    return (m0 > m1 ? (m0 > m3 ? m0 : m3) : (m1 > m3 ? m1 : m3)) + 16;
+}
+
+// ZSAD keeps 96 costs + the 25 left terms + the 5x5 sliding window in registers (~210): its own kernel at two waves per
+// SIMD.  The other three matchers need ~120 registers and run four waves per SIMD (blockIdx.z: NCC, census, Sobel-SAD).
+template <int ND>
+__global__ __launch_bounds__(256, 2) void features_zsad_kernel(FastArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[features_smem_bytes<ND>()];
+    features_px<3, ND>(a, smem);
+}
+template <int ND>
+__global__ __launch_bounds__(256, 4) void features_kernel(FastArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[features_smem_bytes<ND>()];
+    switch (blockIdx.z) {
+    case 0: features_px<1, ND>(a, smem); break;
+    case 1: features_px<0, ND>(a, smem); break;
+    default: features_px<2, ND>(a, smem); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host
+bool volume_fast_supported(const msnet_volume_params& p, int Hb, int Wb, int nd) {
+    if (p.censw != kCW || p.nccw != kNW || p.sobelw != kSW || p.sadw != kZW) return false;
+    if (p.border_h < 6 || p.border_w < 6) return false;    // every window of a cropped pixel is inside the image
+    if (nd % 8 != 0 || nd > 96) return false;
+    if ((size_t)nd * (Hb - 2 * p.border_h) * (Wb - 2 * p.border_w) * 4 > 0xfffffff0u) return false;   // one channel per buffer descriptor
+    if (Wb + 8 > 1200 || Hb > 600) return false;            // LDS band / checkpoint strip of the Sobel-SAD kernels
+    return true;
+}
+
+constexpr int kBandR = 27, kBandNT = 512;
+
+static int band_ls(int Wb) {
+    int LS = Wb + 1;
+    while (LS % 8 != 4) ++LS;
+    return LS;
+}
+
+// bytes of workspace the fast path uses: census bits, NCC tables, four float images, Sobel-SAD checkpoints
+size_t volume_fast_workspace_bytes(int Hb, int Wb, int nd) {
+    const size_t img = (size_t)Hb * Wb;
+    const int Hc = Hb > 12 ? Hb - 12 : 1;                  // at least border 6; more border = fewer bands
+    return img * (2 * 16 + 2 * 16 + 4 * 4) + (size_t)nd * cdiv(Hc, kBandR) * band_ls(Wb) * sizeof(float) + 256;
+}
+
+int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int nd, const msnet_volume_params& p, void* workspace,
+                       float* out, hipStream_t s) {
+    const size_t img = (size_t)Hb * Wb;
+    FastArgs a{};
+    a.l = l; a.r = r;
+    unsigned char* w = (unsigned char*)workspace;          // carve (all 16-byte aligned): bits 2*img*16 | tables 2*img*16 | 4 float images | checkpoints
+    a.lb = (uint4*)w; a.rb = a.lb + img;
+    a.ncl = (double2*)(a.rb + img); a.ncr = a.ncl + img;
+    a.ml = (float*)(a.ncr + img); a.mr = a.ml + img; a.sobl = a.mr + img; a.sobr = a.sobl + img;
+    float* ck = a.sobr + img;
+    a.out = out;
+    a.sigma[0] = p.cens_sigma; a.sigma[1] = p.ncc_sigma; a.sigma[2] = p.sad_sigma; a.sigma[3] = p.sad_sigma;
+    for (int k = 0; k < 4; ++k) a.rsigma[k] = 1.f / a.sigma[k];
+    a.Hb = Hb; a.Wb = Wb; a.nd = nd; a.bh = p.border_h; a.bw = p.border_w;
+    a.Hc = Hb - 2 * p.border_h; a.Wc = Wb - 2 * p.border_w;
+    const size_t plane = (size_t)a.Hc * a.Wc;
+    const dim3 gpix(cdiv(a.Wc, 64), cdiv(a.Hc, 4), 1);
+    {
+        LaunchScope ls("vol_prep", s, 0, 2.0 * img + 72.0 * img);
+        hipLaunchKernelGGL(vprep_kernel, dim3(cdiv(Wb, 64), cdiv(Hb, 4), 3), dim3(256), 0, s, a);
+    }
+    {
+        LaunchScope ls("vol_zsad", s, 0, 4.0 * 2.0 * nd * (double)plane);
+        if (nd <= 32) hipLaunchKernelGGL(features_zsad_kernel<32>, gpix, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(features_zsad_kernel<96>, gpix, dim3(256), 0, s, a);
+    }
+    {
+        const int LS = band_ls(Wb);
+        const int nbands = cdiv(a.Hc, kBandR);
+        const size_t lds = (size_t)(kBandR + kSW) * LS * sizeof(float);
+        if (lds > 160 * 1024) return fail("msnet_build_volume: image width %d too large for the Sobel-SAD band", Wb);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)sadsob_band_kernel<kBandR, kBandNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        float* park = out + (size_t)6 * nd * plane;         // channel 6 = likelihood of the Sobel-SAD cost
+        LaunchScope ls("vol_sadsob", s, 0, 4.0 * nd * (double)plane);
+        const int ck_rows = (nbands - 1) * kBandR + p.border_h - kSW / 2 - 1;     // image rows in front of the last band
+        const size_t ck_lds = (size_t)(ck_rows > 0 ? ck_rows : 1) * 64 * sizeof(float);
+        if (ck_lds > 160 * 1024) return fail("msnet_build_volume: image height %d too large for the Sobel-SAD checkpoint strip", Hb);
+        static bool attr_set2 = false;
+        if (!attr_set2) {
+            (void)hipFuncSetAttribute((const void*)sadsob_ckpt_kernel<kBandR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set2 = true;
+        }
+        hipLaunchKernelGGL(sadsob_ckpt_kernel<kBandR>, dim3(cdiv(LS, 64), nd), dim3(256), ck_lds, s, a, ck, LS, nbands, ck_rows > 0 ? ck_rows : 0);
+        hipLaunchKernelGGL((sadsob_band_kernel<kBandR, kBandNT>), dim3(nd * nbands), dim3(kBandNT), lds, s, a, ck, park, LS, nbands);
+    }
+    {
+        LaunchScope ls("vol_features", s, 0, 4.0 * 6.0 * nd * (double)plane);
+        const dim3 g(gpix.x, gpix.y, 3);
+        if (nd <= 32) hipLaunchKernelGGL(features_kernel<32>, g, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(features_kernel<96>, g, dim3(256), 0, s, a);
+    }
+    return check_launch("msnet_build_volume");
+}
+
+}  // namespace msnet

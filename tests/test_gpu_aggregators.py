@@ -377,38 +377,90 @@ def test_golden_end_to_end(gpu, name, precision):
             assert np.abs(s - gold[key]).max() <= 1e-4 * max(1.0, float(np.abs(gold[key]).max())), key
 
 
-@pytest.mark.parametrize("model_name,in_shape,maxdisp", [("gcnet", (1, 8, 96, 272, 480), 192),
-                                                         ("psmnet", (1, 64, 48, 136, 240), 192)])
-def test_full_benchmark_shape_matches_oracle(gpu, model_name, in_shape, maxdisp):
-    """BASELINE.json configs #2 / #3 at full size (960x544, D=192): HIP (default split-fp16 precision) vs the CPU oracle
-    on the same seeded weights and a random volume; also a size-independent property (disparity inside [0, D-1])."""
-    case = dict(model=model_name, seed=21, maxdisp=maxdisp, in_shape=in_shape)
+def test_full_benchmark_shape_matches_oracle(gpu):
+    """BASELINE.json config #2's aggregator at full size (960x544, D=192): HIP (default split-fp16 precision) vs the CPU
+    oracle on the same seeded weights and a random volume; also a size-independent property (disparity inside [0, D-1]).
+    (tests/test_gpu_configs.py runs the same shape end to end from the images.)"""
+    case = dict(model="gcnet", seed=21, maxdisp=192, in_shape=(1, 8, 96, 272, 480))
     model = recipes.build_case(case, *_our_classes())
     sd = {k: v.clone() for k, v in model.state_dict().items()}
-    x = recipes.make_input(in_shape, 21)
+    x = recipes.make_input(case["in_shape"], 21)
     got = model.cuda()(x.cuda()).cpu()
     torch.set_num_threads(min(64, os.cpu_count() or 1))
     with torch.no_grad():
-        if model_name == "gcnet":
-            ref = oracle.gcnet_forward(sd, x, maxdisp)
-        else:
-            ref = oracle.psmnet_forward(sd, x, maxdisp, recipes.out_hw(case))
+        ref = oracle.gcnet_forward(sd, x, 192)
     err = float((got - ref).abs().max())
-    print("%s full size: max|disp - oracle| = %.3e, range %.2f..%.2f" % (model_name, err, float(ref.min()), float(ref.max())))
+    print("gcnet full size: max|disp - oracle| = %.3e, range %.2f..%.2f" % (err, float(ref.min()), float(ref.max())))
+    assert got.shape == ref.shape == (1, 544, 960)
+    assert float(got.min()) >= 0 and float(got.max()) <= 191
+    assert err <= DISP_TOL
+
+
+def _tail_stats(cost3, maxdisp, out_hw, dtype):
+    """The reference's PSMNet tail (psmnet_3dcnn.py:167-174) on given logits in `dtype`: -> (disparity, kappa) with
+    kappa_i = sum_d |d - disp_i| p_d, the first-order sensitivity of pixel i's disparity to a perturbation of its logits:
+    |delta disp_i| <= kappa_i * max_d |delta logit_d| (softmax-weighted mean; trilinear weights are a convex combination)."""
+    c = F.interpolate(cost3.to(dtype), [maxdisp, out_hw[0], out_hw[1]], mode="trilinear", align_corners=True).squeeze(1)
+    p = F.softmax(c, 1)
+    d = torch.arange(maxdisp, dtype=dtype).view(1, -1, 1, 1)
+    disp = torch.sum(p * d, 1)
+    kappa = torch.sum(p * (d - disp.unsqueeze(1)).abs(), 1)
+    return disp, kappa
+
+
+def test_cfg3_psmnet_full_size(gpu):
+    """BASELINE.json config #3 at full size ([1,64,48,136,240] -> 960x544, D=192), three gates that can each fail:
+
+      G1  the 28-conv trunk: logits cost3 (pre-trilinear, psmnet_3dcnn.py:147) vs the fp32 oracle, relative error <= 1e-5
+          (the golden taps use 1e-4; fp32-vs-fp64 of the oracle itself is 9e-7 here);
+      G2  the tail alone: HIP trilinear+softmax+regression vs torch's fp32 tail ON THE SAME (HIP) LOGITS;
+      G3  end to end vs the fp32 oracle, per pixel: |disp - oracle| <= 1e-3 + kappa_i * (max|delta logits| + eps_tail).
+
+    Why not a flat 1e-3 end to end: with these random-init weights the softmax over D=192 is broad (kappa up to ~80
+    disparities per unit logit), so the oracle's own fp32 tail differs from an fp64 tail ON IDENTICAL LOGITS by 2e-2, and
+    only 43 % of the pixels have |oracle fp32 - oracle fp64| <= 1e-4 (measured in the build container; printed below from
+    the fp64 tail).  kappa is what tells a conditioning effect from a bug: a well-conditioned pixel gets 1e-3."""
+    case = dict(model="psmnet", seed=21, maxdisp=192, in_shape=(1, 64, 48, 136, 240))
+    maxdisp, hw = 192, (544, 960)
+    model = recipes.build_case(case, *_our_classes())
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    x = recipes.make_input(case["in_shape"], 21)
+    taps = {}
+    got = model.cuda()(x.cuda(), taps=taps).cpu()
+    c3 = taps["cost3"].cpu()
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    with torch.no_grad():
+        taps_or = {}
+        ref = oracle.psmnet_forward(sd, x, maxdisp, hw, taps=taps_or)
+        c3_ref = taps_or["cost3"]
+        # G1
+        dl = float((c3 - c3_ref).abs().max())
+        rel = dl / float(c3_ref.abs().max())
+        print("psmnet full size: logits cost3 rel err %.3e (abs %.3e, max|logit| %.1f)" % (rel, dl, float(c3_ref.abs().max())))
+        assert c3.shape == c3_ref.shape == (1, 1, 48, 136, 240)
+        assert rel <= 1e-5
+        # G2: same logits through torch's fp32 tail and an fp64 tail
+        t32, _ = _tail_stats(c3, maxdisp, hw, torch.float32)
+        t64, kappa = _tail_stats(c3, maxdisp, hw, torch.float64)
+    kappa = kappa.float()
+    eps_tail = 8 * 2.0 ** -24 * float(c3.abs().max())         # fp32 rounding of the 7 lerp operations on a logit of this size
+    e_tail = (got - t32).abs()
+    noise32 = (t32.double() - t64).abs().float()
+    print("psmnet full size: tail alone, HIP vs torch-fp32 on the same logits: max %.3e; torch-fp32 vs fp64 tail: max %.3e; "
+          "kappa max %.1f median %.1f" % (float(e_tail.max()), float(noise32.max()), float(kappa.max()), float(kappa.median())))
+    assert float((e_tail - (DISP_TOL + kappa * eps_tail)).max()) <= 0
+    assert float((got.double() - t64).abs().max()) <= float(noise32.max()) + DISP_TOL   # no further from exact than torch's fp32 tail
+    # G3
+    err = (got - ref).abs()
+    tol = DISP_TOL + kappa * (dl + eps_tail)
+    tight = float((tol <= 2 * DISP_TOL).float().mean())
+    print("psmnet full size: max|disp - oracle| = %.3e; per-pixel tolerance 1e-3 + kappa*(%.2e): %.1f%% of pixels gated at "
+          "<= 2e-3, worst err/tol %.3f; pixels with |torch-fp32 - fp64 tail| <= 1e-4: %.1f%%"
+          % (float(err.max()), dl + eps_tail, 100 * tight, float((err / tol).max()), 100 * float((noise32 <= 1e-4).float().mean())))
     assert got.shape == ref.shape == (1, 544, 960)
     assert float(got.min()) >= 0 and float(got.max()) <= maxdisp - 1
-    if err > DISP_TOL:
-        # With these random-init weights the 28-layer PSMNet at D=192 has a sharply peaked softmax and the fp32
-        # reference itself sits ~2e-2 from an fp64 evaluation of the same network (DESIGN.md section 5): the gate becomes
-        # "no further from exact arithmetic than the fp32 reference is".
-        with torch.no_grad():
-            sd64 = {k: v.double() for k, v in sd.items()}
-            ref64 = (oracle.gcnet_forward(sd64, x.double(), maxdisp) if model_name == "gcnet" else
-                     oracle.psmnet_forward(sd64, x.double(), maxdisp, recipes.out_hw(case))).float()
-        noise = float((ref - ref64).abs().max())
-        ours = float((got - ref64).abs().max())
-        print("%s full size: fp32 oracle vs fp64 = %.3e, HIP vs fp64 = %.3e" % (model_name, noise, ours))
-        assert ours <= noise + DISP_TOL
+    assert float((err - tol).max()) <= 0
+    assert tight >= 0.25                                         # the gate is not vacuous
 
 
 def test_gcnet_16_plane_volume(gpu):

@@ -98,6 +98,29 @@ def test_fused_volume_build(gpu, H, W, nd, seed, kind):
     assert got.min() >= 0 and got.max() <= 1
 
 
+@pytest.mark.parametrize("H,W,nd,seed,kind", [(68, 100, 16, 0, "texture"), (40, 150, 32, 3, "extreme"), (57, 93, 8, 2, "flat"),
+                                              (84, 212, 48, 8, "random"), (292, 500, 96, 6, "texture")])
+def test_fast_and_generic_volume_paths_agree(gpu, monkeypatch, H, W, nd, seed, kind):
+    """msnet_build_volume has a register-resident fast path for the reference's own windows (volume_fused.hip) and the
+    run-time-window kernels (volume.hip, forced here with MSNET_VOLUME_GENERIC=1).  Cost channels must be bit-identical
+    between the two and to the oracle; the likelihood channels of the two paths use the same expf and must agree bit for bit
+    wherever the value is a normal float."""
+    from msnets_amd import cbmv_generator as cg
+    l, r = _pair(H, W, nd, seed, kind)
+    monkeypatch.setenv("MSNET_VOLUME_GENERIC", "0")
+    fast = cg.build_ms_volume(l, r, nd)
+    monkeypatch.setenv("MSNET_VOLUME_GENERIC", "1")
+    slow = cg.build_ms_volume(l, r, nd)
+    ref = O.build_ms_volume(l, r, nd)
+    for ch, nm in enumerate(["census", "ncc", "sobel", "sad"]):
+        _bitexact(fast[ch], ref[ch], "fast path, cost channel " + nm)
+        _bitexact(slow[ch], ref[ch], "generic path, cost channel " + nm)
+    # likelihoods: same expf, IEEE division (generic) vs the three-operation division (fast): identical bits except where
+    # the quotient is subnormal (< 1.2e-38), where the fma residual is no longer exact
+    assert np.abs(fast[4:].astype(np.float64) - slow[4:]).max() < 1.2e-38
+    assert np.abs(fast[4:] - ref[4:]).max() <= 2e-6
+
+
 def test_fused_volume_build_other_windows(gpu):
     """Non-default window sizes take the run-time-window kernels."""
     from msnets_amd import cbmv_generator as cg

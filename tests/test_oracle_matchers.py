@@ -150,3 +150,33 @@ def test_get_right_cost_known_answer():
     assert res[1, 4, 1] == cost[0, 0, 0] and res[0, 3, 2] == cost[0, 0, 0]
     feats = O.extract_features_lr(cost, cost / 200 - 1, cost, cost)
     assert feats.shape == (16, 3, 2, 5) and feats.dtype == np.float32
+
+
+def test_three_operation_division_is_the_ieee_quotient():
+    """volume_fused.hip divides by constants (120, sigma) and by the per-pixel likelihood sum with q = a*rb, r = fma(-q, b, a),
+    q' = fma(r, rb, q), rb = RN(1/b) (Markstein).  Emulated here in float64 (products of two float32 are exact in float64;
+    the residual a - q*b cancels to an exactly representable value): the result must equal the IEEE float32 quotient the
+    reference computes -- exhaustively for the census costs 0..121 / 120 and on random operands for the other divisors."""
+    f32 = np.float32
+
+    def div_rn(a, b):
+        a = a.astype(f32); b = f32(b)
+        rb = f32(1.0) / b
+        q = (a * rb).astype(f32)
+        r = (a.astype(np.float64) - q.astype(np.float64) * np.float64(b)).astype(f32)      # fma(-q, b, a): exact, then one rounding
+        return (q.astype(np.float64) + r.astype(np.float64) * np.float64(rb)).astype(f32)   # fma(r, rb, q)
+
+    census = np.arange(0, 122, dtype=f32).clip(0, 120)
+    assert np.array_equal(div_rn(census, 120.0), census / f32(120.0))
+    rng = np.random.default_rng(0)
+    for b in (0.02, 20000.0, 128.0):
+        a = (rng.random(200000, dtype=f32) * f32(1e4)) ** 2
+        a = np.concatenate([a, f32([0.0, 1e-30, 4.6e18, 1.0, 3.0])])
+        assert np.array_equal(div_rn(a, b), a / f32(b)), b
+    den = (rng.random(200000, dtype=f32) * 95 + 1).astype(f32)
+    e = rng.random(200000, dtype=f32)
+    rb = f32(1.0) / den
+    q = (e * rb).astype(f32)
+    r = (e.astype(np.float64) - q.astype(np.float64) * den.astype(np.float64)).astype(f32)
+    got = (q.astype(np.float64) + r.astype(np.float64) * rb.astype(np.float64)).astype(f32)
+    assert np.array_equal(got, e / den)
