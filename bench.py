@@ -299,7 +299,9 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc + ", batch=%d per GPU" % B, "global_batch": n_total,
                        "parallelism": "dp%d (rank-sharded pairs, RCCL all-gather of disparity maps)" % world,
-                       "includes_volume_build": not args.no_volume},
+                       "includes_volume_build": not args.no_volume,
+                       "collective": ("rccl all_gather_into_tensor" if torch.distributed.is_available() and
+                                      torch.distributed.is_initialized() else "none (single process)")},
             "step_ms": {"median": pct(50), "p10": pct(10), "p90": pct(90), "source": "HIP events between steps, rank 0"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -328,6 +330,7 @@ def main():
                 print("  %-22s calls %4d  %9.3f ms/step (%5.1f%%)  %7.1f TFLOP/s  %8.1f GB/s(alg)" % (
                     k, v["calls"], v["ms"] / args.steps, 100 * v["ms"] / tot, tf, gb), file=sys.stderr)
             print("  kernels %.3f ms/step of %.3f ms/step wall" % (tot / args.steps, 1e3 * dt / args.steps), file=sys.stderr)
+            print("  per-step ms (sorted): " + " ".join("%.2f" % t for t in per_step), file=sys.stderr)
         if world == 1 and not args.no_extras:
             pk = measure_peaks(dev)
             line["peaks_measured"] = dict(pk, note="this device, this run: float4 copy of 1 GiB (read + write bytes) and a "

@@ -43,6 +43,16 @@ int         msnet_prof_enable(int on);
 int         msnet_prof_select(const char* name_prefix);
 long        msnet_prof_collect(char* buf_host, size_t buf_bytes);
 
+/* fp16-range guard of the split-fp16 kernels (their operands' `hi` halves are fp16: |x| must stay below 65504).  While a
+ * device word is registered (per calling thread; NULL unregisters) every conv / transposed-conv epilogue and the NCDHW ->
+ * NDHWC conversion of the module input OR 1 into it when they store / read a magnitude >= 65504 (or a non-finite value).
+ * The caller zeroes the word, runs the layers, reads it back; ms-nets_amd/hipops.py re-runs the forward on the exact
+ * fp32 kernels when it is set.  No reference counterpart: torch's fp32 conv has no such range limit. */
+int msnet_set_overflow_flag(void* device_u32);
+/* 1: msnet_deconv5_softargmin and msnet_conv3d_k3_cout1 contract the channels with fp32 FMAs (exact fp32 products, no fp16
+ * range limit) instead of the split-fp16 MFMA; per calling thread; default 0. */
+int msnet_set_exact_tails(int on);
+
 /* Measured-attainable peaks of this device for bench.py's roofline denominators; diagnostics, not on
  * the product path.  msnet_peak_copy: one float4 copy of `bytes` bytes (2 * bytes of HBM traffic).  msnet_peak_mfma_f16:
  * a full-chip grid of waves issuing `iters` x 8 v_mfma_f32_32x32x16_f16 on registers; returns the FLOPs of the call

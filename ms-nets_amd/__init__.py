@@ -10,7 +10,7 @@ Sub-modules mirror the reference's surfaces:
     gcnet_3dcnn.GCNet_CostVolumeAggre, psmnet_3dcnn.PSMNet_CostVolumeAggre   (src/models/*)
     libmatchers, libfeatextract                                             (src/cpp/lib/*)
     cbmv_generator.get_costs / extract_features_left / build_ms_volume       (src/dataloader/cbmv_generator.py)
-    dist.shard_batch / gather_disparities                                    (replaces nn.DataParallel)
+    dist.shard_indices / gather_disparities                                    (replaces nn.DataParallel)
 """
 from . import _lib  # noqa: F401
 

@@ -25,6 +25,8 @@ SIGNATURES = {
     "msnet_prof_enable": (c_int, [c_int]),
     "msnet_prof_select": (c_int, [c_char_p]),
     "msnet_prof_collect": (c_long, [c_char_p, c_size_t]),
+    "msnet_set_overflow_flag": (c_int, [P]),
+    "msnet_set_exact_tails": (c_int, [c_int]),
     "msnet_peak_copy": (c_int, [P, P, c_size_t, P]),
     "msnet_peak_mfma_f16": (ctypes.c_double, [P, c_int, P]),
     "msnet_census": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
@@ -111,6 +113,10 @@ def require_gpu_f32(t, name, dtype=None):
                            % (name, t.device))
     if t.dtype != dtype:
         raise TypeError("%s must be %s (got %s)" % (name, dtype, t.dtype))
+    if t.device.index != torch.cuda.current_device():
+        # kernels launch on the CURRENT device's stream; a tensor of another GPU would be a foreign pointer there
+        raise RuntimeError("%s lives on %s but the current device is cuda:%d (use torch.cuda.set_device / torch.cuda.device)"
+                           % (name, t.device, torch.cuda.current_device()))
     return t.contiguous()
 
 

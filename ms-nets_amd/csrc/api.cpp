@@ -11,6 +11,12 @@
 namespace msnet {
 
 static thread_local char g_err[512] = "";
+static thread_local unsigned* g_oflag = nullptr;
+
+static thread_local bool g_exact_tails = false;
+
+unsigned* overflow_flag() { return g_oflag; }
+bool exact_tails() { return g_exact_tails; }
 
 void set_error(const char* fmt, ...) {
     va_list ap;
@@ -72,6 +78,16 @@ using namespace msnet;
 
 extern "C" int msnet_version(void) { return 1; }
 extern "C" const char* msnet_last_error(void) { return g_err; }
+
+extern "C" int msnet_set_exact_tails(int on) {
+    g_exact_tails = on != 0;
+    return 0;
+}
+
+extern "C" int msnet_set_overflow_flag(void* device_u32) {
+    g_oflag = static_cast<unsigned*>(device_u32);
+    return 0;
+}
 
 extern "C" int msnet_prof_enable(int on) {
     g_prof = on ? 1 : 0;

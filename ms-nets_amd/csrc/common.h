@@ -17,6 +17,8 @@ namespace msnet {
 constexpr float kSentinel = 2147483648.0f;
 
 void set_error(const char* fmt, ...);
+bool exact_tails();               // msnet_set_exact_tails(): tails on fp32 VALU arithmetic instead of the split-fp16 MFMA
+unsigned* overflow_flag();       // the calling thread's msnet_set_overflow_flag() pointer (device memory) or null
 int  fail(const char* fmt, ...);   // set_error + return 1
 
 // Profiling hooks (api.cpp).  Each kernel launch goes through LaunchScope so that, when profiling

@@ -187,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_k3_mfma_ws(ConvArgs a) {
                     const float sh = a.shift ? a.shift[co] : 0.f;
                     const size_t base = ((((size_t)n * a.OD + od) * a.OH + ohb) * a.OW + owb) * a.Co + co;
                     epilogue_block<BW>(acc[i][j], sc, sh, a.res, a.y, base, stride_h, stride_w, a.relu, full_hw,
-                                       [&](int lh, int lw) { return ohb + lh < a.OH && owb + lw < a.OW; });
+                                       [&](int lh, int lw) { return ohb + lh < a.OH && owb + lw < a.OW; }, a.oflag);
                 }
             }
         }
@@ -272,7 +272,7 @@ __device__ __forceinline__ void deconv_class(const float* lds, const int (&abase
             const float sh = a.shift ? a.shift[co] : 0.f;
             const size_t base = ((((size_t)n * a.OD + 2 * id + PD) * a.OH + 2 * ihb + PH) * a.OW + 2 * iwb + PW) * a.Co + co;
             epilogue_block<BW>(acc[i][j], sc, sh, a.res, a.y, base, stride_h, stride_w, a.relu, full_hw,
-                               [&](int lh, int lw) { return ihb + lh < a.H && iwb + lw < a.W; });
+                               [&](int lh, int lw) { return ihb + lh < a.H && iwb + lw < a.W; }, a.oflag);
         }
     }
 }
@@ -392,7 +392,7 @@ extern "C" int msnet_conv3d_k3(const float* x, const float* wpk, const float* sc
     if (!(Ci == 8 || (Ci > 0 && Ci % 16 == 0))) return fail("msnet_conv3d_k3: Ci=%d must be 8 or a multiple of 16", Ci);
     ConvArgs a{};
     a.x = x; a.wpk = reinterpret_cast<const f32x4*>(wpk); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
-    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu; a.oflag = overflow_flag();
     a.OD = (D - 1) / stride + 1; a.OH = (H - 1) / stride + 1; a.OW = (W - 1) / stride + 1;
     hipStream_t s = (hipStream_t)stream;
     const bool two = (Co % 64 == 0);
@@ -429,7 +429,7 @@ extern "C" int msnet_deconv3d_k3s2(const float* x, const float* wpk, const float
     if (Co % 32 != 0 || Co <= 0) return fail("msnet_deconv3d_k3s2: Co=%d must be a positive multiple of 32", Co);
     ConvArgs a{};
     a.x = x; a.wpk = reinterpret_cast<const f32x4*>(wpk); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
-    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu; a.oflag = overflow_flag();
     a.OD = 2 * D; a.OH = 2 * H; a.OW = 2 * W;
     hipStream_t s = (hipStream_t)stream;
     const bool two = (Co % 64 == 0);

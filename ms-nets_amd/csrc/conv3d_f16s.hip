@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 for (int e = 0; e < 16; ++e) v[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
                 const size_t base = ((((size_t)n * a.OD + od) * a.OH + ohb) * a.OW + owb) * a.Co + co;
                 epilogue_block<BW>(v, sc, sh, a.res, a.y, base, stride_h, stride_w, a.relu, full_hw,
-                                   [&](int lh, int lw) { return ohb + lh < a.OH && owb + lw < a.OW; });
+                                   [&](int lh, int lw) { return ohb + lh < a.OH && owb + lw < a.OW; }, a.oflag);
             }
         }
     };
@@ -574,12 +574,15 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 const float sc = a.scale ? a.scale[co] : 1.f;
                 const float sh = a.shift ? a.shift[co] : 0.f;
                 f32x16 t;
+                float amax = 0.f;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     float v = (acc0[i][j][e] + acc1[i][j][e] * kLoInv) * sc + sh;
                     if (a.relu) v = fmaxf(v, 0.f);
+                    amax = fmaxf(amax, fabsf(v));
                     t[e] = v;
                 }
+                flag_overflow(a.oflag, amax);
                 pend[DRAIN ? i : 0][DRAIN ? j : 0] = t;
             }
         }
@@ -1114,7 +1117,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void deconv3d
 #pragma unroll
                     for (int e = 0; e < 16; ++e) v[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
                     epilogue_store<32>(v, rres[0][i][j], sc[j], sh[j], rs_y, obase[0][i][j], 0, stride_w, a.relu,
-                                       [&](int, int lw) { return obase[0][i][j] != 0xffffffffu && lw < wlim[0]; });
+                                       [&](int, int lw) { return obase[0][i][j] != 0xffffffffu && lw < wlim[0]; }, a.oflag);
                 }
         });
     }
@@ -1268,7 +1271,7 @@ __global__ __launch_bounds__(256, 2) void conv3d_c8_f16s_kernel(ConvArgs a) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
                 residual_prefetch<32>(rv, rs_res, off, 0, a.Co * 4, valid);
-                epilogue_store<32>(v, rv, sc, sh, rs_y, off, 0, a.Co * 4, a.relu, valid);
+                epilogue_store<32>(v, rv, sc, sh, rs_y, off, 0, a.Co * 4, a.relu, valid, a.oflag);
             }
         }
     }
@@ -1414,7 +1417,7 @@ __global__ __launch_bounds__(256) void conv3d_direct_f16s_kernel(ConvArgs a, int
     const unsigned off = (unsigned)(((size_t)mblk * 32 + 4 * hh) * a.Co + co) * 4u;
     f32x16 rv;
     residual_prefetch<32>(rv, rs_res, off, 0, a.Co * 4, [](int, int) { return true; });
-    epilogue_store<32>(sum, rv, sc, sh, rs_y, off, 0, a.Co * 4, a.relu, [](int, int) { return true; });
+    epilogue_store<32>(sum, rv, sc, sh, rs_y, off, 0, a.Co * 4, a.relu, [](int, int) { return true; }, a.oflag);
 }
 
 // true if the direct kernel ran (small layer), false if the caller should use a tiled kernel, negative never
@@ -1525,7 +1528,7 @@ extern "C" int msnet_pack_conv_weight_f16s(const float* w, void* packed, int Ci,
     if (!w || !packed) return fail("msnet_pack_conv_weight_f16s: null pointer");
     if (!msnet_conv3d_k3_f16s_supported(Ci, Co, stride))
         return fail("msnet_pack_conv_weight_f16s: unsupported Ci=%d Co=%d stride=%d", Ci, Co, stride);
-    const int KS = (Ci == 8 || stride == 2) ? 1 : 2;    // 16-channel K-steps per staged chunk
+    const int KS = (Ci == 8 || Ci == 16 || stride == 2) ? 1 : 2;    // 16-channel K-steps per staged chunk
     if (Co <= 0 || Co % 32 != 0) return fail("msnet_pack_conv_weight_f16s: Co=%d must be a positive multiple of 32", Co);
     if (Ci == 8) {                                      // first-layer kernel: two taps per K-step
         hipStream_t s8 = (hipStream_t)stream;
@@ -1543,8 +1546,9 @@ extern "C" int msnet_pack_conv_weight_f16s(const float* w, void* packed, int Ci,
 
 extern "C" int msnet_conv3d_k3_f16s_supported(int Ci, int Co, int stride) {
     if (stride == 2) return (Ci > 0 && Ci % 16 == 0 && Co > 0 && Co % 64 == 0) ? 1 : 0;
-    return (stride == 1 && (Ci == 8 || (Ci > 0 && Ci % 32 == 0)) && (Co == 32 || (Co > 0 && Co % 64 == 0)) &&
-            !(Ci == 8 && Co > 64)) ? 1 : 0;
+    // Ci = 16: the left+right matching-space volume (cbmv_in_planes = 16, gcnet_3dcnn.py:58-65) -- one 16-channel K-step per tap
+    return (stride == 1 && (Ci == 8 || Ci == 16 || (Ci > 0 && Ci % 32 == 0)) && (Co == 32 || (Co > 0 && Co % 64 == 0)) &&
+            !((Ci == 8 || Ci == 16) && Co > 64)) ? 1 : 0;
 }
 
 extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const float* scale, const float* shift,
@@ -1556,7 +1560,7 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
         return fail("msnet_conv3d_k3_f16s: unsupported shape Ci=%d Co=%d stride=%d", Ci, Co, stride);
     ConvArgs a{};
     a.x = x; a.wpk = reinterpret_cast<const f32x4*>(wpk_f16s); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
-    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu; a.oflag = overflow_flag();
     a.OD = (D - 1) / stride + 1; a.OH = (H - 1) / stride + 1; a.OW = (W - 1) / stride + 1;
     hipStream_t s = (hipStream_t)stream;
     {   // small layers: one workgroup per 32x32 output block instead of a handful of persistent tile walkers
@@ -1573,6 +1577,10 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
     if (Ci == 8) {
         if (Co == 64) return launch_c8_f16s<2>("conv3d_s1_c8_f16s", a, s);
         return launch_c8_f16s<1>("conv3d_s1_c8_f16s", a, s);
+    }
+    if (Ci == 16) {                                     // single 16-channel chunk, streamed weight groups of 3 K-steps
+        if (Co == 64) return launch_f16s<2, 4, 32, 32, 2, 2, false, 1, false>("conv3d_s1_c16_f16s", a, s);
+        return launch_f16s<2, 4, 32, 32, 2, 1, false, 1, false>("conv3d_s1_c16_f16s", a, s);
     }
     if (Co % 64 == 0) {
         // widths that are 16 mod 32 (240, 120, ...): 16-wide M-block rows leave no half-empty edge tile and a smaller halo
@@ -1612,7 +1620,7 @@ extern "C" int msnet_deconv3d_k3s2_f16s(const float* x, const void* wpk_f16s, co
     if (!msnet_deconv3d_k3s2_f16s_supported(Ci, Co)) return fail("msnet_deconv3d_k3s2_f16s: unsupported Ci=%d Co=%d", Ci, Co);
     ConvArgs a{};
     a.x = x; a.wpk = reinterpret_cast<const f32x4*>(wpk_f16s); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
-    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu; a.oflag = overflow_flag();
     a.OD = 2 * D; a.OH = 2 * H; a.OW = 2 * W;
     const bool tiled_ok = Ci == 64 && (Co == 32 || Co == 64);
     const size_t items = (size_t)cdiv(D, 2) * cdiv(H, 4) * cdiv(W, 32) * (Co / 32);      // per sample (batch-invariant choice)

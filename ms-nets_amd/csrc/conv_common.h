@@ -30,7 +30,16 @@ struct ConvArgs {
     int ngroups;           // Co / (32 * WN * NB)
     int nbtot;             // Co / 32
     int nseg, seglen;      // sliding-window kernels: depth segments per tile column, tiles (depth steps) per segment
+    unsigned* oflag;       // device word that receives 1 when an output leaves the fp16 range (msnet_set_overflow_flag), or null
 };
+
+// Range guard of the split-fp16 kernels (conv3d_f16s.hip: every operand's `hi` half is an fp16): an activation of magnitude
+// >= 65504 cannot be split.  Every epilogue folds the magnitudes it stores into one compare and raises the caller's flag;
+// the Python modules then re-run the forward on the exact fp32 kernels (hipops.py).  16 v_max + 1 compare per 16 outputs.
+constexpr float kF16Max = 65504.f;
+__device__ __forceinline__ void flag_overflow(unsigned* oflag, float amax) {
+    if (oflag && !(amax < kF16Max)) atomicOr(oflag, 1u);      // !(x < max): also catches inf and NaN maxima
+}
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -87,7 +96,8 @@ __device__ __forceinline__ void load_b(f32x4 (&b)[NB], const f32x4* __restrict__
 template <int BW, class Valid>
 __device__ __forceinline__ void epilogue_block(const f32x16& acc, float sc, float sh, const float* __restrict__ res,
                                                float* __restrict__ y, size_t base, int stride_h, int stride_w, int relu,
-                                               bool full, Valid valid) {
+                                               bool full, Valid valid, unsigned* oflag = nullptr) {
+    float amax = 0.f;
     if (full) {
         float rv[16];
         if (res) {
@@ -105,6 +115,7 @@ __device__ __forceinline__ void epilogue_block(const f32x16& acc, float sc, floa
             const int c = (e & 3) + 8 * (e >> 2);
             float v = acc[e] * sc + sh + rv[e];
             if (relu) v = fmaxf(v, 0.f);
+            amax = fmaxf(amax, fabsf(v));
             y[base + (size_t)((c / BW) * stride_h + (c % BW) * stride_w)] = v;
         }
     } else {
@@ -116,10 +127,12 @@ __device__ __forceinline__ void epilogue_block(const f32x16& acc, float sc, floa
                 float v = acc[e] * sc + sh;
                 if (res) v += res[idx];
                 if (relu) v = fmaxf(v, 0.f);
+                amax = fmaxf(amax, fabsf(v));
                 y[idx] = v;
             }
         }
     }
+    flag_overflow(oflag, amax);
 }
 
 // The same epilogue in two halves over buffer descriptors, for kernels that can issue the residual loads long before the
@@ -147,15 +160,19 @@ __device__ __forceinline__ void residual_prefetch(f32x16& rv, __amdgpu_buffer_rs
 template <int BW, class Valid>
 __device__ __forceinline__ void epilogue_store(const f32x16& acc, const f32x16& rv, float sc, float sh,
                                                __amdgpu_buffer_rsrc_t y, unsigned off, int stride_h, int stride_w, int relu,
-                                               Valid valid) {
+                                               Valid valid, unsigned* oflag = nullptr) {
+    float amax = 0.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int c = (e & 3) + 8 * (e >> 2);
-        const unsigned o = valid(c / BW, c % BW) ? off + (unsigned)((c / BW) * stride_h + (c % BW) * stride_w) : 0xffffffffu;
+        const bool ok = valid(c / BW, c % BW);
+        const unsigned o = ok ? off + (unsigned)((c / BW) * stride_h + (c % BW) * stride_w) : 0xffffffffu;
         float v = acc[e] * sc + sh + rv[e];
         if (relu) v = fmaxf(v, 0.f);
+        amax = fmaxf(amax, ok ? fabsf(v) : 0.f);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y, o, 0, 0);
     }
+    flag_overflow(oflag, amax);
 }
 
 // (A voxel-lane variant of this epilogue -- weights as MFMA operand A, so that a lane holds four consecutive channels of

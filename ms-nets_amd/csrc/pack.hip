@@ -27,7 +27,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 // [N][C][S] -> [N][S][C] (S = D*H*W).  One workgroup moves 256 voxels x C channels through LDS so both the
 // reads (along S) and the writes (C-contiguous runs) are coalesced.
 __global__ __launch_bounds__(256) void ncs_to_nsc_kernel(const float* __restrict__ src, float* __restrict__ dst,
-                                                         int C, long S) {
+                                                         int C, long S, unsigned* oflag) {
     extern __shared__ __attribute__((aligned(16))) float tile[];   // [C][LS], LS chosen bank-conflict-free
     const int LS = 256 + (C < 32 ? 32 / C : 1);
     const long s0 = (long)blockIdx.x * 256;
@@ -35,8 +35,10 @@ __global__ __launch_bounds__(256) void ncs_to_nsc_kernel(const float* __restrict
     const int tid = threadIdx.x;
     const int cnt = (int)((S - s0 < 256) ? (S - s0) : 256);
     const float* sp = src + (size_t)n * C * S + s0;
+    float amax = 0.f;                                      // the module input feeds a split-fp16 layer: fp16 range guard
     for (int c = 0; c < C; ++c)
-        if (tid < cnt) tile[c * LS + tid] = sp[(size_t)c * S + tid];
+        if (tid < cnt) { const float v = sp[(size_t)c * S + tid]; amax = fmaxf(amax, fabsf(v)); tile[c * LS + tid] = v; }
+    if (oflag && !(amax < 65504.f)) atomicOr(oflag, 1u);
     __syncthreads();
     float* dp = dst + ((size_t)n * S + s0) * C;
     const int total = cnt * C;
@@ -99,7 +101,7 @@ static int layout_common(bool to_cl, const float* src, float* dst, int N, int C,
     LaunchScope ls(to_cl ? "ncdhw_to_ndhwc" : "ndhwc_to_ncdhw", s, 0, 8.0 * N * C * (double)S);
     if (to_cl) {
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)ncs_to_nsc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(ncs_to_nsc_kernel, grid, dim3(256), lds, s, src, dst, C, S);
+        hipLaunchKernelGGL(ncs_to_nsc_kernel, grid, dim3(256), lds, s, src, dst, C, S, overflow_flag());
     } else {
         if (lds > 65536) (void)hipFuncSetAttribute((const void*)nsc_to_ncs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(nsc_to_ncs_kernel, grid, dim3(256), lds, s, src, dst, C, S);

@@ -11,8 +11,14 @@ namespace msnet {
 typedef _Float16 half8_p __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void peak_copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, size_t n4) {
+    // four independent 16-byte loads per thread in flight before the first store
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        const f32x4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n4; i += stride) dst[i] = src[i];
 }
 
 __global__ __launch_bounds__(256) void peak_mfma_f16_kernel(float* __restrict__ out, int iters, float seed) {
@@ -46,7 +52,7 @@ using namespace msnet;
 
 extern "C" int msnet_peak_copy(const void* src, void* dst, size_t bytes, msnet_stream_t stream) {
     if (!src || !dst || bytes < 16) return fail("msnet_peak_copy: bad arguments");
-    hipLaunchKernelGGL(peak_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, bytes / 16);
+    hipLaunchKernelGGL(peak_copy_kernel, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, bytes / 16);
     return check_launch("msnet_peak_copy");
 }
 

@@ -645,22 +645,19 @@ extern "C" int msnet_deconv5_softargmin(const float* x, const float* w, float bi
     if (!x || !w || !disp) return fail("msnet_deconv5_softargmin: null pointer");
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_deconv5_softargmin: empty input");
     if (Ci != 32) return fail("msnet_deconv5_softargmin: Ci=%d (only 32 is built)", Ci);
-#ifdef TAIL_VALU
+    // exact_tails(): the channel contraction as fp32 FMAs on the vector unit instead of the split-fp16 MFMA (range fallback)
+    const bool valu = exact_tails();
     constexpr int RT = TAIL_RT, CPT = TAIL_CPT, TH = RT * CPT;
-    const int nth = cdiv(H, TH), ntw = cdiv(W, 32);
-#else
-    const int nth = cdiv(H, 7), ntw = cdiv(W, 31);
-#endif
+    const int nth = valu ? cdiv(H, TH) : cdiv(H, 7), ntw = valu ? cdiv(W, 32) : cdiv(W, 31);
     hipStream_t s = (hipStream_t)stream;
     const double vox = (double)N * D * H * W;
     LaunchScope ls("deconv5_softargmin", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + 4.0 * N * H * W));
-#ifdef TAIL_VALU
-    hipLaunchKernelGGL((deconv5_tail_kernel<32, false, RT, CPT>), dim3((unsigned)(N * nth * ntw)), dim3(RT * 32), 0, s, x, w,
-                       bias, disp, N, D, H, W, nth, ntw);
-#else
-    hipLaunchKernelGGL(deconv5_tail_mfma_kernel, dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, bias, disp, N, D, H, W,
-                       nth, ntw);
-#endif
+    if (valu)
+        hipLaunchKernelGGL((deconv5_tail_kernel<32, false, RT, CPT>), dim3((unsigned)(N * nth * ntw)), dim3(RT * 32), 0, s, x, w,
+                           bias, disp, N, D, H, W, nth, ntw);
+    else
+        hipLaunchKernelGGL(deconv5_tail_mfma_kernel, dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, bias, disp, N, D, H, W,
+                           nth, ntw);
     return check_launch("msnet_deconv5_softargmin");
 }
 
@@ -693,15 +690,15 @@ extern "C" int msnet_conv3d_k3_cout1(const float* x, const float* w, const float
     hipStream_t s = (hipStream_t)stream;
     const double vox = (double)N * D * H * W;
     LaunchScope ls("conv3d_cout1", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + vox * (add ? 2 : 1)));
-#ifdef TAIL_VALU
-    const int nth = cdiv(H, 8), ntw = cdiv(W, 32);
-    hipLaunchKernelGGL((conv_cout1_kernel<32>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, add, y, N, D, H,
-                       W, nth, ntw);
-#else
-    const int nth = cdiv(H, 6), ntw = cdiv(W, 30);
-    hipLaunchKernelGGL(conv_cout1_mfma_kernel, dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, add, y, N, D, H, W,
-                       nth, ntw);
-#endif
+    if (exact_tails()) {
+        const int nth = cdiv(H, 8), ntw = cdiv(W, 32);
+        hipLaunchKernelGGL((conv_cout1_kernel<32>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, add, y, N, D, H,
+                           W, nth, ntw);
+    } else {
+        const int nth = cdiv(H, 6), ntw = cdiv(W, 30);
+        hipLaunchKernelGGL(conv_cout1_mfma_kernel, dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, add, y, N, D, H, W,
+                           nth, ntw);
+    }
     return check_launch("msnet_conv3d_k3_cout1");
 }
 

@@ -18,11 +18,17 @@
 // HBM traffic per map: the 8 output channels (401 MB at 960x544, D=192) + the parked Sobel-SAD raw costs (50 MB written,
 // 50 MB read back) + the small tables.  Built with -ffp-contract=off like volume.hip: float32 operation order is part
 // of the reference's result.
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "common.h"
 
 namespace msnet {
 
 constexpr int kCW = 11, kNW = 3, kSW = 5, kZW = 5;      // census / NCC / Sobel-SAD / ZSAD windows of the fast path
+constexpr int kMaxBands = 28;                           // Sobel-SAD row bands per image (host-checked)
+constexpr int kBandRMin = 11;                           // smallest band height any configuration uses (workspace sizing)
 
 struct FastArgs {
     const uint8_t* l; const uint8_t* r;
@@ -126,115 +132,150 @@ __global__ __launch_bounds__(256) void vprep_kernel(FastArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------ Sobel-SAD
-// The reference's vertical pass is one sequential float32 chain per (disparity, column) over all rows.  It is cut into
-// bands of R cropped rows by CHECKPOINTS: sadsob_ckpt_kernel walks every chain once (two cached loads per element, 16 rows
-// of loads in flight) and keeps only the running sum in front of each band; sadsob_band_kernel resumes from there.
-//   ck[(d * nbands + band) * LS + c] = S_vertical[i_lo(band) - 1][c],   i_lo(band) = band * R + border_h - 2
+// The reference's vertical pass is one sequential float32 chain per (disparity, column) over all rows -- but every term
+// |SL - SR_shift| is an integer <= 2040 (Sobel responses are integers in [-1020, 1020]) and a column sums to at most
+// Hb * 2040 < 2^24 (checked on the host: Hb <= 8000), so every partial sum is an exactly representable integer and the ORDER
+// of the vertical additions cannot change a bit.  That makes the vertical pass parallel:
+//   sadsob_bandsum_kernel : bs[(d * nbands + b) * LS + c] = sum of |SL - SR_shift| over the image rows of band slot b
+//                           (slot 0: rows 0 .. first-1, slot b: the R rows in front of band b's first kept integral row)
+//   sadsob_band_kernel    : start value of band b = bs[0] + ... + bs[b], then its own R + 5 rows.
+// The horizontal pass is NOT exact (sums reach 3e8) and keeps the reference's strictly sequential order (matchers.cpp:406-411).
 template <int R>
-__global__ __launch_bounds__(256) void sadsob_ckpt_kernel(FastArgs a, float* __restrict__ ck, int LS, int nbands, int rows) {
-    // Phase 1: all 256 threads fetch |SL - SR_shift| of 64 columns x `rows` image rows into LDS (every load independent, so
-    // the whole strip is in flight at once); phase 2: one thread per column walks its chain out of LDS.
-    extern __shared__ __attribute__((aligned(16))) float A[];     // [rows][64]
-    const int c0 = blockIdx.x * 64;                        // first integral column of the strip
-    const int d = blockIdx.y;
-    const int W = a.Wb;
-    for (int k = threadIdx.x; k < rows * 64; k += 256) {
-        const int i = k >> 6, c = c0 + (k & 63), j = c - 1;
-        float v = 0.f;
-        if (c <= W && j >= d) v = fabsf(a.sobl[i * W + j] - a.sobr[i * W + j - d]);
-        A[k] = v;
+__global__ __launch_bounds__(256) void sadsob_bandsum_kernel(FastArgs a, float* __restrict__ bs, int LS, int nbands) {
+    const int c = blockIdx.x * 256 + threadIdx.x;          // integral column <-> image column c - 1
+    const int b = blockIdx.y, d = blockIdx.z;
+    if (c >= LS) return;
+    const int W = a.Wb, H = a.Hb;
+    const int j = c - 1;
+    float sum = 0.f;
+    if (c <= W && j >= d) {
+        const int first = a.bh - kSW / 2 - 1;              // image rows in front of band 0's first kept integral row
+        const int r0 = b == 0 ? 0 : first + (b - 1) * R, r1 = first + b * R;      // image rows [r0, r1)
+        const float* pl = a.sobl + j;
+        const float* pr = a.sobr + j - d;
+        float v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) { const int row = min(r0 + k, H - 1); v[k] = fabsf(pl[row * W] - pr[row * W]); }
+#pragma unroll
+        for (int k = 0; k < R; ++k) if (r0 + k < r1) sum += v[k];
     }
-    __syncthreads();
-    const int c = c0 + threadIdx.x;
-    if (threadIdx.x >= 64 || c >= LS) return;
-    float* o = ck + (size_t)d * nbands * LS + c;
-    float run = 0.f;                                       // columns with j < d only ever add +0
-    int i = 0;
-    for (int b = 0; b < nbands; ++b) {
-        const int target = b * R + a.bh - kSW / 2 - 1;     // image rows 0 .. target-1 make integral row i_lo(b) - 1
-        for (; i < target; ++i) run = A[i * 64 + threadIdx.x] + run;
-        o[(size_t)b * LS] = run;
-    }
+    bs[((size_t)d * nbands + b) * LS + c] = sum;
 }
 
 // Workgroup = (disparity d, band of R cropped rows).  LDS holds the R + 5 integral rows the band's boxes touch, row
 // stride LS with LS % 8 == 4 so that `lane = row` ds_read_b128 / ds_write_b128 accesses are conflict-free: vertical pass
-// (thread = column, resumed from the checkpoint), horizontal pass (lane = row, strictly sequential from column d+1,
-// matchers.cpp:406-411), then the 5x5 boxes.  `park` receives the raw box costs [nd][Hc][Wc] (kSentinel where the
-// reference leaves RAND_MAX).  The float32 integral image itself never goes to HBM.
+// (thread = column), horizontal pass (lane = row, strictly sequential from column d+1), then the 5x5 boxes.  `park` receives
+// the raw box costs [nd][Hc][Wc] (kSentinel where the reference leaves RAND_MAX).  The integral image never goes to HBM.
 template <int R, int NT>
-__global__ __launch_bounds__(NT) void sadsob_band_kernel(FastArgs a, const float* __restrict__ ck, float* __restrict__ park, int LS,
-                                                         int nbands) {
+__global__ __launch_bounds__(NT) void sadsob_band_kernel(FastArgs a, const float* __restrict__ bs, float* __restrict__ park, int LS,
+                                                         int nbands, int skip) {
     extern __shared__ __attribute__((aligned(16))) float S[];     // [R + 5][LS]
     constexpr int NR = R + kSW;
+    static_assert(NR <= 64 && NR % 8 == 0, "band rows: one lane per row, vertical pass in batches of 8");
     const int d = blockIdx.x / nbands;
     const int band = blockIdx.x % nbands;
     const int yc0 = band * R;                              // first cropped row of the band
     const int W = a.Wb, H = a.Hb;
     const int i_lo = yc0 + a.bh - kSW / 2;                 // first integral row kept  (= window top of the band's first row)
-    const int i_hi = min(i_lo + NR - 1, H);                // last integral row kept
     const int tid = threadIdx.x;
 
-    // vertical pass: S[i][c] = S[i-1][c] + |SL[i-1][c-1] - SR[i-1][c-1-d]|, image rows i_lo-1 .. i_hi-1
+    // vertical pass: S[i][c] = S[i-1][c] + |SL[i-1][c-1] - SR[i-1][c-1-d]| for the NR integral rows i_lo .. i_lo+NR-1 (rows
+    // past the image repeat the last row's term: they are never read by a box)
+    if (!(skip & 1))
     for (int c = tid; c < LS; c += NT) {
         const int j = c - 1;
-        if (c > W || j < d) {
-            for (int rr = 0; rr <= i_hi - i_lo; ++rr) S[rr * LS + c] = 0.f;
-            continue;
+        float run = 0.f;
+        const bool live = c <= W && j >= d;                // other columns stay zero, as the reference leaves them
+        if (live) {
+            const float* q = bs + (size_t)d * nbands * LS + c;
+            float t[kMaxBands];                            // all loads in flight at once (a dependent chain would pay 26 L2 latencies)
+#pragma unroll
+            for (int b = 0; b < kMaxBands; ++b) t[b] = q[(size_t)min(b, band) * LS];
+#pragma unroll
+            for (int b = 0; b < kMaxBands; ++b) if (b <= band) run += t[b];       // exact integers (see above)
         }
-        const float* pl = a.sobl + j;
-        const float* pr = a.sobr + j - d;
-        float run = ck[((size_t)d * nbands + band) * LS + c];
-        for (int i = i_lo - 1; i < i_hi; i += 16) {
+        const float* pl = a.sobl + (live ? j : 0);
+        const float* pr = a.sobr + (live ? j - d : 0);
+#pragma unroll
+        for (int i0 = 0; i0 < NR; i0 += 16) {
             float v[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) { const int row = min(i + k, H - 1); v[k] = fabsf(pl[row * W] - pr[row * W]); }
+            for (int k = 0; k < 16; ++k) {
+                if (i0 + k < NR) { const int row = min(i_lo - 1 + i0 + k, H - 1); v[k] = fabsf(pl[row * W] - pr[row * W]); }
+            }
 #pragma unroll
-            for (int k = 0; k < 16; ++k)
-                if (i + k < i_hi) { run = v[k] + run; S[(i + k + 1 - i_lo) * LS + c] = run; }
+            for (int k = 0; k < 16; ++k) {
+                if (i0 + k < NR) { run = live ? v[k] + run : 0.f; S[(i0 + k) * LS + c] = run; }
+            }
         }
     }
     __syncthreads();
 
-    // horizontal pass
+    // horizontal pass: 16 columns per step; the reads of the next step are issued before this step's 16 dependent additions
     const int c_last = min(W, W - a.bw + kSW);             // last integral column any cropped box reads
-    if (tid < 64 && tid <= i_hi - i_lo) {
+    if (!(skip & 2) && tid < NR) {
         float* row = S + tid * LS;
         float run = 0.f;
         int c = (d + 1) & ~3;                              // columns <= d hold zeros: adding them keeps run == 0
         auto rd = [&](int cc) { return *reinterpret_cast<const f32x4*>(row + min(cc, LS - 4)); };
-        f32x4 v0 = rd(c), v1 = rd(c + 4), v2 = rd(c + 8);  // three reads ahead of the add chain (LDS latency)
-        for (; c <= c_last; c += 4) {
-            const f32x4 nx = rd(c + 12);
-            run = v0[0] + run; v0[0] = run;
-            run = v0[1] + run; v0[1] = run;
-            run = v0[2] + run; v0[2] = run;
-            run = v0[3] + run; v0[3] = run;
-            *reinterpret_cast<f32x4*>(row + c) = v0;
-            v0 = v1; v1 = v2; v2 = nx;
+        auto step = [&](f32x4 (&v)[4], f32x4 (&nx)[4], int cc) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nx[q] = rd(cc + 16 + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q][0] = v[q][0] + run; v[q][1] = v[q][1] + v[q][0]; v[q][2] = v[q][2] + v[q][1]; v[q][3] = v[q][3] + v[q][2];
+                run = v[q][3];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (cc + 4 * q < LS) *reinterpret_cast<f32x4*>(row + cc + 4 * q) = v[q];
+        };
+        f32x4 va[4], vb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) va[q] = rd(c + 4 * q);
+        for (; c <= c_last; c += 32) {                     // two steps per iteration: the buffers swap roles without copies
+            step(va, vb, c);
+            if (c + 16 <= c_last) step(vb, va, c + 16);
+            else break;
         }
     }
     __syncthreads();
 
-    // boxes: cost(y, x) = S[b][r] - S[b][l] - S[t][r] + S[t][l], window top-left (y-2, x-2)
+    // boxes: cost(y, x) = S[b][r] - S[b][l] - S[t][r] + S[t][l], window top-left (y-2, x-2); four outputs per thread in flight
     const size_t plane = (size_t)a.Hc * a.Wc;
     const int rows = min(R, a.Hc - yc0);
+    const int nout = rows * a.Wc;
+    float* const obase = park + (size_t)d * plane + (size_t)yc0 * a.Wc;     // the band's outputs are contiguous: [rows][Wc]
+    const int off = a.bw - kSW / 2;
     int rr = 0, x = tid;
     while (x >= a.Wc) { x -= a.Wc; ++rr; }
-    while (rr < rows) {
-        const float* t = S + rr * LS;
-        const float* b = t + kSW * LS;
-        const int j = x + a.bw - kSW / 2;
-        float c = kSentinel;
-        if (j >= d) {
-            float q = b[j + kSW] - b[j];
-            q = q - t[j + kSW];
-            q = q + t[j];
-            c = q;
+    if (!(skip & 4))
+    for (int p0 = tid; p0 < nout; p0 += 4 * NT) {
+        float tl[4], tr[4], bl[4], br[4];
+        int jj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = p0 + u * NT < nout;
+            const int j = x + off;
+            const float* t = S + (ok ? rr : 0) * LS + (ok ? j : 0);
+            tl[u] = t[0]; tr[u] = t[kSW]; bl[u] = t[kSW * LS]; br[u] = t[kSW * LS + kSW];
+            jj[u] = j;
+            x += NT;
+            while (x >= a.Wc) { x -= a.Wc; ++rr; }
         }
-        park[(size_t)d * plane + (size_t)(yc0 + rr) * a.Wc + x] = c;
-        x += NT;
-        while (x >= a.Wc) { x -= a.Wc; ++rr; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (p0 + u * NT < nout) {
+                float c = kSentinel;
+                if (jj[u] >= d) {
+                    float q = br[u] - bl[u];
+                    q = q - tr[u];
+                    q = q + tl[u];
+                    c = q;
+                }
+                obase[p0 + u * NT] = c;
+            }
+        }
     }
 }
 
@@ -489,6 +530,18 @@ __global__ __launch_bounds__(256, 2) void features_zsad_kernel(FastArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[features_smem_bytes<ND>()];
     features_px<3, ND>(a, smem);
 }
+// all four matchers in one launch at three waves per SIMD (blockIdx.z: ZSAD, NCC, census, Sobel-SAD): the VALU-bound ZSAD
+// waves share the CUs with the store-bound ones
+template <int ND>
+__global__ __launch_bounds__(256, 3) void features4_kernel(FastArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[features_smem_bytes<ND>()];
+    switch (blockIdx.z) {
+    case 0: features_px<3, ND>(a, smem); break;
+    case 1: features_px<1, ND>(a, smem); break;
+    case 2: features_px<0, ND>(a, smem); break;
+    default: features_px<2, ND>(a, smem); break;
+    }
+}
 template <int ND>
 __global__ __launch_bounds__(256, 4) void features_kernel(FastArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[features_smem_bytes<ND>()];
@@ -505,11 +558,11 @@ bool volume_fast_supported(const msnet_volume_params& p, int Hb, int Wb, int nd)
     if (p.border_h < 6 || p.border_w < 6) return false;    // every window of a cropped pixel is inside the image
     if (nd % 8 != 0 || nd > 96) return false;
     if ((size_t)nd * (Hb - 2 * p.border_h) * (Wb - 2 * p.border_w) * 4 > 0xfffffff0u) return false;   // one channel per buffer descriptor
-    if (Wb + 8 > 1200 || Hb > 600) return false;            // LDS band / checkpoint strip of the Sobel-SAD kernels
+    if (Wb + 8 > 1200) return false;                        // LDS band of the Sobel-SAD kernel (32 rows x (Wb + 8) floats)
+    if (cdiv(Hb - 2 * p.border_h, kBandRMin) > kMaxBands) return false;   // band table of the Sobel-SAD kernels
+    if (Hb > 8000) return false;                            // exact vertical sums: Hb * 2040 < 2^24 (sadsob_bandsum_kernel)
     return true;
 }
-
-constexpr int kBandR = 27, kBandNT = 512;
 
 static int band_ls(int Wb) {
     int LS = Wb + 1;
@@ -521,7 +574,7 @@ static int band_ls(int Wb) {
 size_t volume_fast_workspace_bytes(int Hb, int Wb, int nd) {
     const size_t img = (size_t)Hb * Wb;
     const int Hc = Hb > 12 ? Hb - 12 : 1;                  // at least border 6; more border = fewer bands
-    return img * (2 * 16 + 2 * 16 + 4 * 4) + (size_t)nd * cdiv(Hc, kBandR) * band_ls(Wb) * sizeof(float) + 256;
+    return img * (2 * 16 + 2 * 16 + 4 * 4) + (size_t)nd * cdiv(Hc, kBandRMin) * band_ls(Wb) * sizeof(float) + 256;
 }
 
 int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int nd, const msnet_volume_params& p, void* workspace,
@@ -545,35 +598,46 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
         LaunchScope ls("vol_prep", s, 0, 2.0 * img + 72.0 * img);
         hipLaunchKernelGGL(vprep_kernel, dim3(cdiv(Wb, 64), cdiv(Hb, 4), 3), dim3(256), 0, s, a);
     }
-    {
+    static const bool merged = [] { const char* e = getenv("MSNET_VOL_MERGED"); return !(e && e[0] == '0'); }();   // default: one launch for the four matchers
+    if (!merged) {
         LaunchScope ls("vol_zsad", s, 0, 4.0 * 2.0 * nd * (double)plane);
         if (nd <= 32) hipLaunchKernelGGL(features_zsad_kernel<32>, gpix, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(features_zsad_kernel<96>, gpix, dim3(256), 0, s, a);
     }
     {
         const int LS = band_ls(Wb);
-        const int nbands = cdiv(a.Hc, kBandR);
-        const size_t lds = (size_t)(kBandR + kSW) * LS * sizeof(float);
-        if (lds > 160 * 1024) return fail("msnet_build_volume: image width %d too large for the Sobel-SAD band", Wb);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)sadsob_band_kernel<kBandR, kBandNT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
         float* park = out + (size_t)6 * nd * plane;         // channel 6 = likelihood of the Sobel-SAD cost
+        static const int band_skip = [] { const char* e = getenv("MSNET_BAND_SKIP"); return e ? atoi(e) : 0; }();     // diagnostic: skip phases
+        static const int band_cfg = [] { const char* e = getenv("MSNET_BAND_CFG"); return e ? atoi(e) : 0; }();       // tuning: band height / threads
         LaunchScope ls("vol_sadsob", s, 0, 4.0 * nd * (double)plane);
-        const int ck_rows = (nbands - 1) * kBandR + p.border_h - kSW / 2 - 1;     // image rows in front of the last band
-        const size_t ck_lds = (size_t)(ck_rows > 0 ? ck_rows : 1) * 64 * sizeof(float);
-        if (ck_lds > 160 * 1024) return fail("msnet_build_volume: image height %d too large for the Sobel-SAD checkpoint strip", Hb);
-        static bool attr_set2 = false;
-        if (!attr_set2) {
-            (void)hipFuncSetAttribute((const void*)sadsob_ckpt_kernel<kBandR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set2 = true;
-        }
-        hipLaunchKernelGGL(sadsob_ckpt_kernel<kBandR>, dim3(cdiv(LS, 64), nd), dim3(256), ck_lds, s, a, ck, LS, nbands, ck_rows > 0 ? ck_rows : 0);
-        hipLaunchKernelGGL((sadsob_band_kernel<kBandR, kBandNT>), dim3(nd * nbands), dim3(kBandNT), lds, s, a, ck, park, LS, nbands);
+        auto launch = [&](auto rc, auto ntc) -> int {
+            constexpr int R = decltype(rc)::value, NT = decltype(ntc)::value;
+            const int nbands = cdiv(a.Hc, R);
+            if (nbands > kMaxBands) return fail("msnet_build_volume: %d Sobel-SAD bands (max %d)", nbands, kMaxBands);
+            const size_t lds = (size_t)(R + kSW) * LS * sizeof(float);
+            if (lds > 160 * 1024) return fail("msnet_build_volume: image width %d too large for the Sobel-SAD band", Wb);
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute((const void*)sadsob_band_kernel<R, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(sadsob_bandsum_kernel<R>, dim3(cdiv(LS, 256), nbands, nd), dim3(256), 0, s, a, ck, LS, nbands);
+            hipLaunchKernelGGL((sadsob_band_kernel<R, NT>), dim3(nd * nbands), dim3(NT), lds, s, a, ck, park, LS, nbands, band_skip);
+            return 0;
+        };
+        int rc = 0;
+        if (band_cfg == 1) rc = launch(std::integral_constant<int, 27>{}, std::integral_constant<int, 256>{});
+        else if (band_cfg == 2) rc = launch(std::integral_constant<int, 11>{}, std::integral_constant<int, 256>{});
+        else if (band_cfg == 3) rc = launch(std::integral_constant<int, 59>{}, std::integral_constant<int, 512>{});
+        else rc = launch(std::integral_constant<int, 27>{}, std::integral_constant<int, 512>{});
+        if (rc) return rc;
     }
-    {
+    if (merged) {
+        LaunchScope ls("vol_features", s, 0, 4.0 * 8.0 * nd * (double)plane);
+        const dim3 g(gpix.x, gpix.y, 4);
+        if (nd <= 32) hipLaunchKernelGGL(features4_kernel<32>, g, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(features4_kernel<96>, g, dim3(256), 0, s, a);
+    } else {
         LaunchScope ls("vol_features", s, 0, 4.0 * 6.0 * nd * (double)plane);
         const dim3 g(gpix.x, gpix.y, 3);
         if (nd <= 32) hipLaunchKernelGGL(features_kernel<32>, g, dim3(256), 0, s, a);

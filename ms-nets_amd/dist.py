@@ -38,8 +38,9 @@ def shard_indices(n_total, rank, world):
 def gather_disparities(local_disp, n_total):
     """local_disp [n_local, H, W] on every rank -> [n_total, H, W] in original sample order on every rank.
     Ranks with one sample fewer (n_total not divisible by world) are padded for the collective."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return local_disp
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_disp                                      # plain single-process run: nothing to gather
+    # (an initialised group of ONE rank still goes through the collective: that is how a 1-GPU box exercises the RCCL path)
     world = dist.get_world_size()
     n_max = (n_total + world - 1) // world
     _, H, W = local_disp.shape

@@ -11,6 +11,8 @@ Contract kept from the reference:
 Not kept: training-mode BatchNorm / autograd (the path is forward-only) and the CPU code path -- there is
 no fallback: without libmsnet_hip.so or a GPU tensor the forward raises.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -68,12 +70,26 @@ class GCNet_CostVolumeAggre(nn.Module):
         net_init(self)
         self._plan = None
         self._plan_key = None
+        # fp16-range guard of the split-fp16 kernels (hipops.guarded_forward): costs one 4-byte read-back per forward;
+        # set range_check = False when the activations are known to stay below 65504
+        self.range_check = os.environ.get("MSNET_RANGE_CHECK", "1") != "0"
+        self._forced_precision = None
+        self._guard = None
+        self._arena = hipops.Arena()      # activation buffers reused across forwards (hipops.Arena)
+        self._use_arena = True
 
     # ---- device constants ------------------------------------------------------------------------
-    def _plans(self):
-        key = hipops.state_key(self) + (hipops.get_default_precision(),)
+    def invalidate_plans(self):
+        """Drop the packed weights / folded BN constants; the next forward rebuilds them from the current parameters.
+        Needed only after edits through `.data` (which leave no trace in the tensors' version counters)."""
+        self._plan = None
+        self._plan_key = None
+        self._forced_precision = None
+
+    def _plans(self, precision):
+        key = hipops.state_key(self) + (precision,)
         if self._plan is None or key != self._plan_key:
-            P = hipops.ConvBNPlan
+            P = lambda *a, **k: hipops.ConvBNPlan(*a, precision=precision, **k)      # noqa: E731
             plan = {"conv3dbn_1": P(*self.conv3dbn_1), "conv3dbn_2": P(*self.conv3dbn_2)}
             for b in ("block_3d_1", "block_3d_2", "block_3d_3", "block_3d_4"):
                 blk = getattr(self, b)
@@ -95,7 +111,13 @@ class GCNet_CostVolumeAggre(nn.Module):
         cv = hipops.require_gpu_f32(cv, "cv")
         if cv.dim() != 5:
             raise ValueError("cv must be [N,C,D,H,W]")
-        pl = self._plans()
+        self._use_arena = taps is None          # tapped activations are handed to the caller: fresh tensors
+        return hipops.guarded_forward(self, lambda precision: self._forward(cv, taps, precision))
+
+    def _forward(self, cv, taps, precision):
+        pl = self._plans(precision)
+        if taps is not None:
+            taps.clear()
 
         def tap(name, t):
             if taps is not None:

@@ -2,16 +2,74 @@
 memory (torch.empty) and the current HIP stream; all arithmetic happens in libmsnet_hip.so.
 
 Internal activation layout is channels-last fp32 [N, D, H, W, C] ("NDHWC")."""
+import warnings
+
 import torch
 
 from . import _lib
 from ._lib import check, ptr, require_gpu_f32, stream_ptr
 
 
+class Arena:
+    """Activation buffers of one module, reused from forward to forward: the k-th buffer request of a forward gets the tensor
+    the k-th request of the previous forward got (same shape, same device), so a steady-state forward allocates nothing --
+    neither hipMalloc nor the caching allocator (whose occasional re-segmentation of the ~6 GB / map it hands out showed up
+    as one 40 ms step in ten).  Buffers are internal activations only; what a module returns is always a fresh tensor.
+    One forward at a time per module (buffers are stream-ordered on the caller's stream)."""
+
+    def __init__(self):
+        self.bufs = []
+        self.k = 0
+
+    def empty(self, shape, device):
+        shape = tuple(int(v) for v in shape)
+        if self.k < len(self.bufs) and tuple(self.bufs[self.k].shape) == shape and self.bufs[self.k].device == device:
+            t = self.bufs[self.k]
+        else:
+            t = torch.empty(shape, device=device, dtype=torch.float32)
+            if self.k < len(self.bufs):
+                self.bufs[self.k] = t
+            else:
+                self.bufs.append(t)
+        self.k += 1
+        return t
+
+    def nbytes(self):
+        return sum(t.numel() * 4 for t in self.bufs)
+
+
+_arena = None
+
+
+class use_arena:
+    """Context: activation outputs of the wrappers below come from `arena` (None = plain torch.empty)."""
+
+    def __init__(self, arena):
+        self.arena = arena
+
+    def __enter__(self):
+        global _arena
+        self.prev, _arena = _arena, self.arena
+        if self.arena is not None:
+            self.arena.k = 0
+        return self.arena
+
+    def __exit__(self, *exc):
+        global _arena
+        _arena = self.prev
+        return False
+
+
+def _new(shape, device):
+    if _arena is not None:
+        return _arena.empty(shape, device)
+    return torch.empty(shape, device=device, dtype=torch.float32)
+
+
 def ncdhw_to_ndhwc(x):
     x = require_gpu_f32(x, "x")
     n, c, d, h, w = x.shape
-    y = torch.empty((n, d, h, w, c), device=x.device, dtype=torch.float32)
+    y = _new((n, d, h, w, c), x.device)
     check(_lib.load().msnet_ncdhw_to_ndhwc(ptr(x), ptr(y), n, c, d, h, w, stream_ptr()), "msnet_ncdhw_to_ndhwc")
     return y
 
@@ -46,6 +104,7 @@ def pack_conv_weight(w, transposed=False, f16s=False, stride=1):
     return out
 
 
+F16S_MAX = 65504.0      # largest finite fp16: |operand| of a split-fp16 kernel must stay below it (hi = fp16(x))
 PRECISIONS = ("fp32", "split-fp16")
 _default_precision = "split-fp16"
 # Transposed convs with a split-fp16 kernel use it: Ci = 64 on the tiled kernel (1.22 vs 1.99 ms on deconvbn4, 0.28 vs
@@ -70,7 +129,7 @@ def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16
     x = require_gpu_f32(x, "x")
     n, d, h, w, ci = x.shape
     od, oh, ow = (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1
-    y = torch.empty((n, od, oh, ow, co), device=x.device, dtype=torch.float32)
+    y = _new((n, od, oh, ow, co), x.device)
     if residual is not None:
         residual = require_gpu_f32(residual, "residual")
         if residual.shape != y.shape:
@@ -84,7 +143,7 @@ def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16
 def deconv3d_k3s2(x, wpk, scale, shift, co, relu=False, residual=None, f16s=False):
     x = require_gpu_f32(x, "x")
     n, d, h, w, ci = x.shape
-    y = torch.empty((n, 2 * d, 2 * h, 2 * w, co), device=x.device, dtype=torch.float32)
+    y = _new((n, 2 * d, 2 * h, 2 * w, co), x.device)
     if residual is not None:
         residual = require_gpu_f32(residual, "residual")
         if residual.shape != y.shape:
@@ -100,7 +159,7 @@ def conv3d_k3_cout1(x, w, add=None):
     x = require_gpu_f32(x, "x")
     w = require_gpu_f32(w, "weight")
     n, d, h, wd, ci = x.shape
-    y = torch.empty((n, d, h, wd), device=x.device, dtype=torch.float32)
+    y = _new((n, d, h, wd), x.device)
     if add is not None:
         add = require_gpu_f32(add, "add")
         if add.shape != y.shape:
@@ -133,7 +192,7 @@ def deconv3d_cout1(x, w, bias, stride=2):
     x = require_gpu_f32(x, "x")
     w = require_gpu_f32(w, "weight")
     n, d, h, wd, ci = x.shape
-    y = torch.empty((n, stride * d, stride * h, stride * wd), device=x.device, dtype=torch.float32)
+    y = _new((n, stride * d, stride * h, stride * wd), x.device)
     check(_lib.load().msnet_deconv3d_cout1(ptr(x), ptr(w), float(bias), ptr(y), n, d, h, wd, ci, stride, stream_ptr()),
           "msnet_deconv3d_cout1")
     return y
@@ -147,6 +206,68 @@ def trilinear_softargmin(cost, out_dhw):
     check(_lib.load().msnet_trilinear_softargmin(ptr(cost), ptr(disp), n, d, h, w, D, H, W, stream_ptr()),
           "msnet_trilinear_softargmin")
     return disp
+
+
+class RangeGuard:
+    """fp16-range guard for one forward on the split-fp16 kernels: registers a device word with the library
+    (msnet_set_overflow_flag); every conv epilogue and the input layout conversion raise it when they see a magnitude the
+    split (hi = fp16(x)) cannot represent.  `tripped()` reads it back (one 4-byte device-to-host copy = one sync per forward)."""
+
+    def __init__(self, device):
+        self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+
+    def __enter__(self):
+        self.flag.zero_()
+        check(_lib.load().msnet_set_overflow_flag(ptr(self.flag)), "msnet_set_overflow_flag")
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().msnet_set_overflow_flag(None)
+        return False
+
+    def tripped(self):
+        return bool(int(self.flag.item()))
+
+
+class exact_tails:
+    """Context: deconv5 / classification-head kernels contract channels with fp32 FMAs instead of the split-fp16 MFMA."""
+
+    def __enter__(self):
+        _lib.load().msnet_set_exact_tails(1)
+
+    def __exit__(self, *exc):
+        _lib.load().msnet_set_exact_tails(0)
+        return False
+
+
+def guarded_forward(module, run):
+    """Shared by the two aggregators.  run(precision) -> output.  On the split-fp16 path the forward runs under a
+    RangeGuard; if an activation (or the input) left the fp16 range the result is discarded, a warning is issued and the
+    forward is repeated on the exact fp32-input MFMA kernels with fp32 tails -- and the module stays there (sticky until
+    invalidate_plans()), so a checkpoint with large activations costs the sync and the double forward once."""
+    precision = module._forced_precision or _default_precision
+    run_ = run
+
+    def run(prec):                      # activations come from the module's arena (not when taps are handed out)
+        with use_arena(module._arena if module._use_arena else None):
+            return run_(prec)
+    if precision != "split-fp16":
+        with exact_tails():
+            return run(precision)
+    if not module.range_check:
+        return run(precision)
+    guard = module._guard
+    if guard is None or guard.flag.device != next(module.parameters()).device:
+        guard = module._guard = RangeGuard(next(module.parameters()).device)
+    with guard:
+        out = run(precision)
+    if guard.tripped():
+        warnings.warn("msnet: an activation left the fp16 range (|x| >= 65504) of the split-fp16 conv kernels; this forward "
+                      "was repeated on the exact fp32 MFMA kernels, which this module now keeps using", RuntimeWarning)
+        module._forced_precision = "fp32"
+        with exact_tails():
+            out = run("fp32")
+    return out
 
 
 class ConvBNPlan:
@@ -173,16 +294,28 @@ class ConvBNPlan:
         else:
             self.scale = None
             self.shift = None if conv.bias is None else conv.bias.detach().float().contiguous()
-        if self.f16s and self.scale is not None:
+        if self.f16s:
             # split-fp16 kernels: the BN scale goes into the packed weights (one fp32 multiply per weight before the
             # hi/lo split) and the shift becomes the accumulators' start value, so their epilogue has no constants.
             shape = (1, -1, 1, 1, 1) if transposed else (-1, 1, 1, 1, 1)
-            w = w.float() * self.scale.view(shape)
-            self.scale = None
+            wf = w.float() * self.scale.view(shape) if self.scale is not None else w.float()
+            # fp16 range of the `hi` half: a folded weight beyond it (tiny running_var, huge gamma) would become inf.
+            # Such a layer stays on the exact fp32-input MFMA kernel (one host sync per plan build, not per forward).
+            wmax = float(wf.abs().max())
+            if not wmax < F16S_MAX:
+                warnings.warn("msnet: folded conv weight magnitude %.3g exceeds the fp16 range of the split-fp16 kernels; "
+                              "this layer runs on the fp32 MFMA kernel" % wmax, RuntimeWarning)
+                self.f16s = False
+            else:
+                w = wf
+                if self.scale is not None:
+                    self.scale = None
         self.wpk = pack_conv_weight(w, transposed, f16s=self.f16s, stride=stride)
 
 
 def state_key(module):
-    """Cheap fingerprint of a module's parameters/buffers: plans are rebuilt when any of them changes
-    (load_state_dict, .to(), in-place edits all bump _version or data_ptr)."""
-    return tuple((t.data_ptr(), t._version, str(t.device)) for t in module.state_dict(keep_vars=True).values())
+    """Cheap fingerprint of a module's parameters/buffers (data pointer, version counter, device): the packed weights and BN
+    plans are rebuilt when it changes.  load_state_dict, .to(), copy_ and every autograd-visible in-place op bump it.
+    Edits made THROUGH `.data` (p.data.mul_(2), the idiom of the reference's net_init.py) do NOT bump the version counter;
+    after such an edit call `model.invalidate_plans()`."""
+    return tuple((t.data_ptr(), t._version, t.device.index) for t in list(module.parameters()) + list(module.buffers()))

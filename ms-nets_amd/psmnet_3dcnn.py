@@ -10,6 +10,8 @@ possible meaning is the full-resolution image, so forward takes ``out_hw`` and d
 Training-mode BatchNorm / autograd are not provided (forward-only path); ``forward_all_heads`` returns the
 three predictions the reference returns in training mode, computed with eval-mode statistics.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -64,11 +66,23 @@ class PSMNet_CostVolumeAggre(nn.Module):
         net_init(self)
         self._plan = None
         self._plan_key = None
+        self.range_check = os.environ.get("MSNET_RANGE_CHECK", "1") != "0"          # fp16-range guard of the split-fp16 kernels, see hipops.guarded_forward
+        self._forced_precision = None
+        self._guard = None
+        self._arena = hipops.Arena()      # activation buffers reused across forwards (hipops.Arena)
+        self._use_arena = True
 
-    def _plans(self):
-        key = hipops.state_key(self) + (hipops.get_default_precision(),)
+    def invalidate_plans(self):
+        """Drop the packed weights / folded BN constants; the next forward rebuilds them from the current parameters.
+        Needed only after edits through `.data` (which leave no trace in the tensors' version counters)."""
+        self._plan = None
+        self._plan_key = None
+        self._forced_precision = None
+
+    def _plans(self, precision):
+        key = hipops.state_key(self) + (precision,)
         if self._plan is None or key != self._plan_key:
-            P = hipops.ConvBNPlan
+            P = lambda *a, **k: hipops.ConvBNPlan(*a, precision=precision, **k)      # noqa: E731
             pl = {"dres0.0": P(*self.dres0[0]), "dres0.2": P(*self.dres0[2]),
                   "dres1.0": P(*self.dres1[0]), "dres1.2": P(*self.dres1[2])}
             for h in ("dres2", "dres3", "dres4"):
@@ -86,8 +100,10 @@ class PSMNet_CostVolumeAggre(nn.Module):
             self._plan, self._plan_key = pl, key
         return self._plan
 
-    def _trunk(self, cost, taps):
-        pl = self._plans()
+    def _trunk(self, cost, taps, precision):
+        pl = self._plans(precision)
+        if taps is not None:
+            taps.clear()
 
         def tap(name, t):
             if taps is not None:
@@ -138,13 +154,19 @@ class PSMNet_CostVolumeAggre(nn.Module):
     def forward(self, cost, out_hw=None, taps=None):
         cost = self._check(cost)
         H, W = out_hw if out_hw is not None else (4 * cost.shape[3], 4 * cost.shape[4])
-        with torch.no_grad():
-            _, _, cost3 = self._trunk(cost, taps)
-            return hipops.trilinear_softargmin(cost3, (self.maxdisp, H, W))
+        def run(precision):
+            with torch.no_grad():
+                _, _, cost3 = self._trunk(cost, taps, precision)
+                return hipops.trilinear_softargmin(cost3, (self.maxdisp, H, W))
+        self._use_arena = taps is None           # tapped activations are handed to the caller: fresh tensors
+        return hipops.guarded_forward(self, run)
 
     def forward_all_heads(self, cost, out_hw=None):
         """(pred1, pred2, pred3) as the reference's training-mode return (psmnet_3dcnn.py:149-177)."""
         cost = self._check(cost)
         H, W = out_hw if out_hw is not None else (4 * cost.shape[3], 4 * cost.shape[4])
-        with torch.no_grad():
-            return tuple(hipops.trilinear_softargmin(c, (self.maxdisp, H, W)) for c in self._trunk(cost, None))
+        def run(precision):
+            with torch.no_grad():
+                return tuple(hipops.trilinear_softargmin(c, (self.maxdisp, H, W)) for c in self._trunk(cost, None, precision))
+        self._use_arena = True
+        return hipops.guarded_forward(self, run)

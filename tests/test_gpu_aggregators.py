@@ -61,6 +61,9 @@ F16S_CASES = [
     (8, 32, (1, 6, 10, 37), True, False),
     (8, 32, (2, 4, 8, 32), False, True),
     (8, 64, (1, 3, 5, 33), True, False),
+    (16, 32, (1, 5, 9, 37), True, False),
+    (16, 32, (2, 4, 8, 32), False, True),
+    (16, 64, (1, 3, 6, 33), True, True),
     (32, 32, (1, 4, 9, 40), True, False),
     (32, 32, (2, 3, 8, 16), True, True),
     (32, 64, (1, 5, 6, 19), True, False),
@@ -464,8 +467,8 @@ def test_cfg3_psmnet_full_size(gpu):
 
 
 def test_gcnet_16_plane_volume(gpu):
-    """cbmv_in_planes=16 (the left+right volume of SURVEY 8(f).2): the first layer then has 16 input channels, which has
-    no split-fp16 kernel and runs on the fp32 MFMA; everything else as usual.  Checked against the oracle."""
+    """cbmv_in_planes=16 (the left+right volume of SURVEY 8(f).2): the first layer then has 16 input channels -- one
+    16-channel K-step per tap on the split-fp16 kernel (conv3d_s1_c16_f16s).  Checked against the oracle."""
     from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre
     torch.manual_seed(3)
     model = GCNet_CostVolumeAggre(maxdisp=32, cbmv_in_planes=16).eval()
@@ -473,7 +476,9 @@ def test_gcnet_16_plane_volume(gpu):
     x = torch.rand((1, 16, 16, 16, 48), generator=torch.Generator().manual_seed(4))
     with torch.no_grad():
         ref = oracle.gcnet_forward(sd, x, 32)
-    got = model.cuda()(x.cuda()).cpu()
+    model = model.cuda()
+    got = model(x.cuda()).cpu()
+    assert model._plans("split-fp16")["conv3dbn_1"].f16s        # the 16-channel layer is on the split-fp16 path
     assert tuple(got.shape) == tuple(ref.shape) == (1, 32, 96)
     assert float((got - ref).abs().max()) <= DISP_TOL
 
@@ -525,6 +530,128 @@ def test_reference_checkpoint_keys_load(gpu):
         ref = oracle.gcnet_forward(b.state_dict(), x.cpu(), 32)
     assert float((d1.cpu() - ref).abs().max()) <= DISP_TOL
     assert float((d1 - d0).abs().max()) > 1e-3
+
+
+def test_data_edits_need_invalidate_plans(gpu):
+    """Edits through `.data` do not bump a tensor's version counter, so the plan cache cannot see them (hipops.state_key);
+    `invalidate_plans()` is the documented way to pick them up.  copy_ / load_state_dict are seen without it."""
+    G, _ = _our_classes()
+    torch.manual_seed(0)
+    m = G(32).eval().cuda()
+    x = torch.rand(1, 8, 16, 16, 32).cuda()
+    d0 = m(x).clone()
+    m.deconv5.weight.data.mul_(3.0)
+    m.invalidate_plans()
+    d1 = m(x).clone()
+    assert float((d1 - d0).abs().max()) > 1e-3
+    with torch.no_grad():
+        ref = oracle.gcnet_forward({k: v.cpu() for k, v in m.state_dict().items()}, x.cpu(), 32)
+    assert float((d1.cpu() - ref).abs().max()) <= DISP_TOL
+    with torch.no_grad():
+        m.conv3dbn_2[0].weight.mul_(0.5)                  # a tracked in-place op: seen without invalidate_plans()
+    d2 = m(x)
+    assert float((d2 - d1).abs().max()) > 1e-4
+
+
+def _big_activation_model(scale):
+    """A GCNet whose conv3dbn_2 output (= res_l20) is `scale` times larger than usual while everything downstream of it is
+    scaled back (its two consumers' weights / scale), so the network stays well conditioned and only the activation range
+    changes."""
+    G, _ = _our_classes()
+    torch.manual_seed(11)
+    m = G(32).eval()
+    recipes.randomize_bn(m, 11)
+    with torch.no_grad():
+        m.conv3dbn_2[1].weight.mul_(scale)
+        m.conv3dbn_2[1].bias.mul_(scale)
+        m.block_3d_1.convbn_3d_1[0].weight.div_(scale)
+        m.deconvbn4[1].weight.mul_(scale)          # keep deconvbn4's own term visible next to the large skip connection
+        m.deconvbn4[1].bias.mul_(scale)
+        m.deconv5.weight.div_(scale)
+    return m
+
+
+def test_fp16_range_guard_reruns_on_fp32(gpu):
+    """Activations of ~1e6 cannot be split into fp16 hi + lo (hi = inf).  The epilogues raise the library's overflow flag, the
+    module warns, repeats the forward on the exact fp32 kernels and stays on them; the result matches the oracle.  With the
+    guard switched off the same forward is garbage -- which is what the guard is for."""
+    from msnets_amd import hipops
+    assert hipops.get_default_precision() == "split-fp16"
+    m = _big_activation_model(3.0e5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.rand((1, 8, 16, 16, 32), generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        ref = oracle.gcnet_forward(sd, x, 32)
+    m = m.cuda()
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        got = m(x.cuda()).cpu()
+    assert m._forced_precision == "fp32"
+    assert float((got - ref).abs().max()) <= DISP_TOL
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                  # second call: already on fp32, no new warning, no re-run
+        again = m(x.cuda()).cpu()
+    assert torch.equal(again, got)
+    m.invalidate_plans()                                # back to split-fp16 ...
+    m.range_check = False                               # ... without the guard
+    bad = m(x.cuda()).cpu()
+    assert not bool(torch.isfinite(bad).all()) or float((bad - ref).abs().max()) > 1.0
+    # in-range activations never trip it
+    G, _ = _our_classes()
+    torch.manual_seed(1)
+    ok = G(32).eval().cuda()
+    import warnings as w2
+    with w2.catch_warnings():
+        w2.simplefilter("error")
+        ok(x.cuda())
+    assert ok._forced_precision is None
+
+
+def test_fp16_range_of_folded_weights(gpu):
+    """A BN scale that pushes a folded weight beyond 65504 (tiny running_var / huge gamma): that layer is planned on the fp32
+    MFMA kernel (with a warning) instead of producing an infinite `hi` half."""
+    from msnets_amd import hipops
+    G, _ = _our_classes()
+    torch.manual_seed(13)
+    m = G(32).eval()
+    recipes.randomize_bn(m, 13)
+    with torch.no_grad():
+        m.block_3d_2.convbn_3d_2[1].weight.mul_(1.0e7)
+        m.block_3d_2.convbn_3d_2[1].bias.mul_(1.0e7)
+        m.block_3d_2.convbn_3d_3[0].weight.div_(1.0e7)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.rand((1, 8, 16, 16, 32), generator=torch.Generator().manual_seed(14))
+    with torch.no_grad():
+        ref = oracle.gcnet_forward(sd, x, 32)
+    m = m.cuda()
+    with pytest.warns(RuntimeWarning):
+        got = m(x.cuda()).cpu()
+    assert bool(torch.isfinite(got).all())
+    assert float((got - ref).abs().max()) <= DISP_TOL
+
+
+def test_activation_arena_reuse(gpu):
+    """Steady-state forwards allocate no activation memory (hipops.Arena): same buffers, same result; what the module returns
+    is a fresh tensor every time; a different input shape re-sizes the arena; taps bypass it."""
+    G, _ = _our_classes()
+    torch.manual_seed(2)
+    m = G(32).eval().cuda()
+    x = torch.rand(2, 8, 16, 16, 32).cuda()
+    d0 = m(x)
+    ptrs = [t.data_ptr() for t in m._arena.bufs]
+    assert len(ptrs) >= 19 and m._arena.nbytes() > 0
+    d1 = m(x)
+    assert [t.data_ptr() for t in m._arena.bufs] == ptrs
+    assert d1.data_ptr() != d0.data_ptr() and torch.equal(d0, d1)
+    assert d0.data_ptr() not in ptrs
+    taps = {}
+    d2 = m(x, taps=taps)
+    assert float((d2 - d0).abs().max()) < 1e-4              # the tapped forward uses the un-fused tail: rounding-level difference
+    assert all(v.data_ptr() not in ptrs for v in taps.values())
+    y = torch.rand(1, 8, 16, 32, 32).cuda()
+    ref = m(y).clone()
+    assert torch.equal(m(x), d0)                              # back to the first shape
+    assert torch.equal(m(y), ref)
 
 
 def test_errors(gpu):

@@ -20,9 +20,9 @@ def _run(*extra):
 
 
 def test_bench_json_contract(gpu):
-    d = _run("--no-cpu-baseline")
+    d = _run("--no-cpu-baseline", "--no-extras")
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "roofline_volume", "step_ms"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1 and d["higher_is_better"] is True
     assert d["unit"] == "maps/s" and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
@@ -32,9 +32,40 @@ def test_bench_json_contract(gpu):
     assert r["bound"] in ("mfma", "hbm") and r["unit"] in ("TFLOP/s", "GB/s") and r["launches"] >= 2
     assert 0.05 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["traffic"] is None or r["traffic"] > 1e9
+    v = d["roofline_volume"]
+    assert v["bound"] == "hbm" and v["unit"] == "GB/s" and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-9
+    assert abs(v["algorithmic_bytes_per_map"] - (8 * 96 * 272 * 480 * 4 + 2 * 292 * 500)) < 1
+    assert 0 < d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
+
+
+def test_bench_extras(gpu):
+    d = _run("--no-cpu-baseline", "--steps", "3")
+    assert d["fp32_exact"]["value"] > 0 and d["fp32_exact"]["value"] < d["value"]
+    pk = d["peaks_measured"]
+    assert 2000 < pk["hbm_copy_GBs"] < 8000 and 800 < pk["mfma_f16_TFLOPs"] < 2600
+    assert 0 < d["roofline"]["frac_attainable"] < 1 and 0 < d["roofline_volume"]["frac_attainable"] < 1
 
 
 def test_bench_cpu_baseline_leg(gpu):
     d = _run("--workload", "cfg1")
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "maps/s" and c["sample"]
+
+
+def test_bench_under_torchrun_uses_rccl(gpu):
+    """One rank under torch.distributed.run: the process group is RCCL (backend "nccl"), the all-gather of the disparity maps
+    runs on the device and bench.py's own ordering check (gathered sample i == rank i % world's local map) passes.  What a
+    1-GPU box can prove of the multi-GPU path; the 1 -> 8 GPU curve needs an 8-GPU node."""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-extras", "--batch-per-gpu", "2"],
+                         cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 2 and d["value"] > 0
+    assert d["config"]["collective"] == "rccl all_gather_into_tensor"
