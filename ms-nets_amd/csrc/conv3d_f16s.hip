@@ -69,13 +69,42 @@ __device__ __forceinline__ void stamp(int role, int& idx, int lane) {
 constexpr float kLoScale = 2048.f;          // 2^11
 constexpr float kLoInv = 1.f / 2048.f;
 
-__device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
+// hi = fp16(x), lo = fp16((x - hi) * 2^11) for four values in TEN vector instructions (hipcc's own code for the plain C++ form
+// below takes 16: it converts hi back to fp32 and multiplies separately): two packed conversions, four mixed-precision fmas
+// that read the fp16 half directly (x - hi is exact in fp32), four fmas that scale, round to fp16 and write one half each.
+// Bit-identical to the C++ form (tools/split_test.hip checks 8M random / denormal / large values on the device).
+// Only for values that go to LDS next: hipcc cannot see what an asm statement executes, so it would not pad the wait states an
+// MFMA needs behind a VALU write of its operand (the direct kernel, which feeds split values straight into MFMAs, read stale
+// registers with this form) -- split4_cxx below is for those.
+__device__ __forceinline__ void split4_cxx(const f32x4 v, half4& hi, half4& lo) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const _Float16 h = (_Float16)v[k];
         hi[k] = h;
         lo[k] = (_Float16)((v[k] - (float)h) * kLoScale);
     }
+}
+__device__ __forceinline__ void split4(const f32x4 v, half4& hi, half4& lo) {
+#ifdef EXP_SPLIT_CXX
+    split4_cxx(v, hi, lo);
+#else
+    unsigned h01, h23, l01, l23;
+    float t0, t1, t2, t3;
+    const float k = kLoScale;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h01) : "v"(v[0]), "v"(v[1]));
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h23) : "v"(v[2]), "v"(v[3]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t0) : "v"(h01), "v"(v[0]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t1) : "v"(h01), "v"(v[1]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(t2) : "v"(h23), "v"(v[2]));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(t3) : "v"(h23), "v"(v[3]));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(l01) : "v"(t0), "v"(k));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(l01) : "v"(t1), "v"(k));
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(l23) : "v"(t2), "v"(k));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(l23) : "v"(t3), "v"(k));
+    struct U2 { unsigned a, b; };
+    hi = __builtin_bit_cast(half4, U2{h01, h23});
+    lo = __builtin_bit_cast(half4, U2{l01, l23});
+#endif
 }
 
 // Packed split weights, in 16-byte units (KS = 16-channel K-steps per chunk: 2 for Ci % 32 == 0, 1 for Ci = 8 which
@@ -493,6 +522,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     }
 
     // ------------------------------ MFMA waves ------------------------------
+#ifdef EXP_MFMA_PRIO
+    __builtin_amdgcn_s_setprio(EXP_MFMA_PRIO);          // experiment: static priority of the MFMA waves over the loader waves
+#endif
     const int wm = wave;                                // WM = 4, WN = 1
     const int r = lane & 31, hh = lane >> 5;
     int vox0[MB];                                       // LDS voxel index of this lane's output voxel (tap 0,0,0)
@@ -1386,8 +1418,8 @@ __global__ __launch_bounds__(256) void conv3d_direct_f16s_kernel(ConvArgs a, int
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             half4 h0, l0, h1, l1;
-            split4(x0[kk], h0, l0);
-            split4(x1[kk], h1, l1);
+            split4_cxx(x0[kk], h0, l0);              // operands of the MFMAs right below: compiler-scheduled form (hazards)
+            split4_cxx(x1[kk], h1, l1);
             const half8 ah = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
             const half8 al = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
             const half8 bh = __builtin_bit_cast(half8, wb[kk][0]), bl = __builtin_bit_cast(half8, wb[kk][1]);

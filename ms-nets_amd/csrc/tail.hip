@@ -23,6 +23,8 @@ namespace msnet {
 
 typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
 // x = hi + lo * 2^-11 with hi = fp16(x), lo = fp16((x - hi) * 2^11): the operand split of the conv kernels
+// (plain C++ on purpose: the halves feed MFMAs directly, and hipcc pads MFMA operand hazards only for instructions it can see --
+// the ten-instruction inline-asm form of conv3d_f16s.hip's split4 is for values that go through LDS)
 __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, half8_t& hi, half8_t& lo) {
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
