@@ -56,9 +56,9 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
 
 #ifdef EXP_STAMP
 // Diagnostic build only: cycle stamps of block 0 (wave 0 = MFMA, wave 4 = loader) at every barrier of the first items.
-__device__ unsigned long long g_stamps[2][256];
+__device__ unsigned long long g_stamps[8][128];      // [wave][stamp]
 __device__ __forceinline__ void stamp(int role, int& idx, int lane) {
-    if (blockIdx.x == 0 && lane == 0 && idx < 256) g_stamps[role][idx] = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && lane == 0 && idx < 128) g_stamps[role][idx] = __builtin_amdgcn_s_memtime();
     ++idx;
 }
 #define STAMP(role, idx, lane) stamp(role, idx, lane)
@@ -142,6 +142,34 @@ __global__ void pack_weight_f16s_kernel(const float* __restrict__ w, _Float16* _
     }
 }
 
+// Work-item counter of the persistent kernels.  Item `it` of a workgroup is (unit = lb + (it / per_unit) * G, pos = it % per_unit)
+// and a unit is a mixed-radix number (channel group, w tile, h tile, d tile or depth segment, sample).  Decoding that from `it`
+// costs six integer divisions by run-time values per item -- ~250 instructions, in waves that share a SIMD with an MFMA wave
+// (and once more per weight group for the weight stream's address).  Items are visited in order, so the digits are ADVANCED
+// instead: the stride G is decomposed once, `next()` is a handful of scalar add / compare / select.
+struct TileCtr {
+    int pos, cg, tw, th, td, n;                         // td: depth tile (plain kernels) or depth segment (sliding window)
+    int s_cg, s_tw, s_th, s_td, s_n;                    // digits of the stride G
+    int ncg, ntw, nth, ntd, per_unit;
+    __device__ __forceinline__ void init(unsigned lb, unsigned G, int ncg_, int ntw_, int nth_, int ntd_, int per_unit_) {
+        ncg = ncg_; ntw = ntw_; nth = nth_; ntd = ntd_; per_unit = per_unit_;
+        unsigned t = lb;
+        cg = t % ncg; t /= ncg; tw = t % ntw; t /= ntw; th = t % nth; t /= nth; td = t % ntd; n = t / ntd;
+        t = G;
+        s_cg = t % ncg; t /= ncg; s_tw = t % ntw; t /= ntw; s_th = t % nth; t /= nth; s_td = t % ntd; s_n = t / ntd;
+        pos = 0;
+    }
+    __device__ __forceinline__ void next() {
+        if (++pos < per_unit) return;
+        pos = 0;
+        cg += s_cg;      int c = cg >= ncg; cg -= c ? ncg : 0;
+        tw += s_tw + c;  c = tw >= ntw;     tw -= c ? ntw : 0;
+        th += s_th + c;  c = th >= nth;     th -= c ? nth : 0;
+        td += s_td + c;  c = td >= ntd;     td -= c ? ntd : 0;
+        n += s_n + c;
+    }
+};
+
 // SWZ = false: 144-byte voxel records (16 B pad): with 1x32-voxel M-blocks every ds_read_b128 lane group hits 16
 //               distinct bank slots and all fragment addresses are base + immediate (no VALU in the MFMA stream).
 // SWZ = true : 128-byte records with the 16-byte slots XOR-swizzled by (tile column >> 1) & 7 -- same conflict-freeness in
@@ -196,26 +224,14 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     if (nitems == 0) return;
     const u32x4* wg = reinterpret_cast<const u32x4*>(a.wpk);     // split-fp16 packed weights
 
-    auto decode_g = [&](int it, int& n, int& od0, int& oh0, int& ow0, int& chunk, int& cg) {
-        unsigned t = lb + (unsigned)(it / per_unit) * G;
-        chunk = SLIDE ? 0 : it % nchunks;
-        cg = t % ncg; t /= ncg;
-        ow0 = (t % a.ntw) * TW; t /= a.ntw;
-        oh0 = (t % a.nth) * TH; t /= a.nth;
-        if (SLIDE) {
-            od0 = ((t % a.nseg) * a.seglen + it % a.seglen) * TD;
-            n = t / a.nseg;
-        } else {
-            od0 = (t % a.ntd) * TD;
-            n = t / a.ntd;
-        }
+    // coordinates of the item a counter points at
+    auto coords = [&](const TileCtr& c, int& n, int& od0, int& oh0, int& ow0, int& chunk, int& cg) {
+        n = c.n; cg = c.cg; ow0 = c.tw * TW; oh0 = c.th * TH;
+        chunk = SLIDE ? 0 : c.pos;
+        od0 = SLIDE ? (c.td * a.seglen + c.pos) * TD : c.td * TD;
     };
-    auto decode = [&](int it, int& n, int& od0, int& oh0, int& ow0, int& chunk) {
-        int cg_;
-        decode_g(it, n, od0, oh0, ow0, chunk, cg_);
-    };
-    // SLIDE: item `it` continues the column of item it-1 iff it is not the first of its segment
-    auto continues = [&](int it) { return SLIDE && it > 0 && (it % per_unit) != 0; };
+    TileCtr ctr0;
+    ctr0.init(lb, G, ncg, a.ntw, a.nth, SLIDE ? a.nseg : a.ntd, per_unit);
 
     if (wave >= 4) {
         // ------------------------------ loader waves ------------------------------
@@ -280,11 +296,14 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         const size_t sample_bytes = (size_t)a.D * a.H * a.W * a.Ci * 4;
 
         struct Coord { int n, od0, oh0, ow0, chunk; };
-        auto coord_of = [&](int it) {
+        auto coord_of = [&](const TileCtr& t) {
             Coord c;
-            decode(it, c.n, c.od0, c.oh0, c.ow0, c.chunk);
+            int cg_;
+            coords(t, c.n, c.od0, c.oh0, c.ow0, c.chunk, cg_);
             return c;
         };
+        TileCtr cur = ctr0, nxt = ctr0;                 // the current item and the one after it
+        nxt.next();
         // request slots [u0, u1) of plane pl of the tile at c
         auto issue_a = [&](const Coord& c, int pl, int u0, int u1) {
             const int gd = c.od0 * STRIDE - 1 + pl;
@@ -338,20 +357,23 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         // Weight groups form one endless stream k = it*9 + g (chunk = it % nchunks).  Group k lives in register set
         // k % PD from the moment it is requested (while group k-PD-1 is multiplied, i.e. ~PD group times = several L2
         // latencies earlier) until it is copied into LDS buffer k & 1 (while group k-1 is multiplied).
-        const int ngroups_total = nitems * 9;
-        auto b_src = [&](int k) {
-            k = k < ngroups_total ? k : ngroups_total - 1;     // past the end: harmless re-read
-            const int it_ = k / 9;
-            const unsigned cg = ncg == 1 ? 0u : (lb + (unsigned)(it_ / per_unit) * G) % (unsigned)ncg;
-            return wg + (size_t)((cg * nchunks + (SLIDE ? 0 : it_ % nchunks)) * 9 + (k % 9)) * PG;
+        // j = group index relative to the CURRENT item's first group (0..8: this item, 9..17: the next one; past the last
+        // item the counter runs on and the read is a harmless one of some valid group)
+        auto b_src = [&](int j) {
+            const TileCtr& t = j < 9 ? cur : nxt;
+            return wg + (size_t)((t.cg * nchunks + (SLIDE ? 0 : t.pos)) * 9 + (j < 9 ? j : j - 9)) * PG;
         };
         // piece index of this thread's u-th piece (clamped for the partial last piece of a 384-piece group)
         int bi_[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) bi_[u] = (PG % LT == 0 || u * LT + lt < PG) ? u * LT + lt : PG - 1;
+#ifdef EXP_BGLOB
+#define MSNET_ISSUE_B(K, SET) do { (void)(SET); } while (0)
+#define MSNET_WRITE_B(K, SET) do { (void)(SET); } while (0)
+#else
 #define MSNET_ISSUE_B(K, SET)                                                                                      \
     do {                                                                                                           \
-        const u32x4* src_ = b_src(K);                                                                              \
+        const u32x4* src_ = b_src((K) - k0);                                                                       \
         SET.v0 = src_[bi_[0]]; SET.v1 = src_[bi_[1]];                                                              \
         if constexpr (NLB > 2) SET.v2 = src_[bi_[2]];                                                              \
         if constexpr (NLB > 3) { SET.v3 = src_[3 * LT + lt]; SET.v4 = src_[4 * LT + lt]; SET.v5 = src_[5 * LT + lt]; }    \
@@ -363,13 +385,14 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         if constexpr (NLB > 2) dst_[bi_[2]] = SET.v2;                                                              \
         if constexpr (NLB > 3) { dst_[3 * LT + lt] = SET.v3; dst_[4 * LT + lt] = SET.v4; dst_[5 * LT + lt] = SET.v5; }    \
     } while (0)
+#endif
 #ifndef EXP_NO_GROUP_BARRIER
 #define MSNET_GROUP(G, SET)                     \
     MSNET_WRITE_B(k0 + (G) + 1, SET);           \
     MSNET_ISSUE_B(k0 + (G) + 1 + 3, SET);       \
-    if (wave == 4) STAMP(1, sidx, lane);        \
+    STAMP(wave, sidx, lane);                    \
     MSNET_LDS_BARRIER();                        \
-    if (wave == 4) STAMP(1, sidx, lane);
+    STAMP(wave, sidx, lane);
 #else
 #define MSNET_GROUP(G, SET)                     \
     MSNET_WRITE_B(k0 + (G) + 1, SET);           \
@@ -387,7 +410,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 for (int p = lt; p < PG; p += LT) dst[p] = src[p];
             }
             {
-                const Coord c0 = coord_of(0);
+                const Coord c0 = coord_of(cur);
 #pragma unroll
                 for (int pl = 0; pl < ID; ++pl) issue_a(c0, pl, 0, PL);
             }
@@ -397,21 +420,25 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 for (int pl = 0; pl < ID; ++pl) write_a(pl, 0, PL);
                 MSNET_LDS_BARRIER();                    // b2
                 if (it + 1 < nitems) {
-                    const Coord c = coord_of(it + 1);
+                    const Coord c = coord_of(nxt);
 #pragma unroll
                     for (int pl = 0; pl < ID; ++pl) issue_a(c, pl, 0, PL);
                 }
+                nxt.next();
             }
             return;
         }
         {
-            const Coord c0 = coord_of(0);
+            const Coord c0 = coord_of(cur);
 #pragma unroll
             for (int pl = 0; pl < ID; ++pl) issue_a(c0, pl, 0, PL);
         }
-        MSNET_ISSUE_B(0, bw0);
-        MSNET_ISSUE_B(1, bw1);
-        MSNET_ISSUE_B(2, bw2);
+        {
+            const int k0 = 0;
+            MSNET_ISSUE_B(0, bw0);
+            MSNET_ISSUE_B(1, bw1);
+            MSNET_ISSUE_B(2, bw2);
+        }
         if constexpr (SLIDE) {
             constexpr int H0 = (PL + 2) / 3, H1 = (2 * PL + 2) / 3, HH = (PL + 1) / 2;
             bool early = false;                         // planes 0,1 of this column-start item were copied during the previous item
@@ -420,10 +447,26 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             for (int it = 0; it < nitems; ++it) {
                 const int k0 = it * 9;
                 const bool more = it + 1 < nitems;
-                const bool cs = !continues(it);         // the current item starts a column: its planes 2,3 (0,1) are not resident
+                const bool cs = cur.pos == 0;           // the current item starts a column: its planes 2,3 (0,1) are not resident
                 if (!cs) rot ^= 1;
-                const bool ncont = more && continues(it + 1);
+                const bool ncont = more && nxt.pos != 0;
+                // Next item: a continuation needs only its logical planes 2,3 (into the slots of this item's planes 0,1, dead
+                // after groups 2 / 5); a column start needs all four (0,1 into those slots, 2,3 in its own b1/b2 window).
+                const Coord nx = coord_of(nxt);
+#ifdef EXP_HOIST
+                // Experiment (measured, not shipped): inside a column, request the next tile's two new planes HERE, before b1,
+                // instead of during groups 0 / 1.  The per-wave stamps (tools_stamps.py) show the loader's groups 0 and 1 taking
+                // ~2600 cycles against ~1450 for the MFMA waves, which wait ~1100 cycles at each of those two barriers; hoisted,
+                // those waits disappear but the same ~1000 cycles reappear as a wait at b1 and the MFMA waves' own hand-over code
+                // slows down (the two waves of a SIMD share its issue port): 2.32 vs 2.29 ms on conv3dbn_2.
+                const bool hoist = ncont && !cs;
+#else
+                const bool hoist = false;
+#endif
+                if (hoist) { issue_a(nx, 2, 0, PL); issue_a(nx, 3, 0, PL); }
+                STAMP(wave, sidx, lane);
                 MSNET_LDS_BARRIER();                    // b1: MFMA waves are done with the previous tile
+                STAMP(wave, sidx, lane);
                 wrot = rot;
                 if (cs) {
                     if (!early) { write_a(0, 0, PL); write_a(1, 0, PL); }
@@ -431,14 +474,13 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 }
                 MSNET_WRITE_B(k0, bw0);
                 MSNET_ISSUE_B(k0 + 3, bw0);
+                STAMP(wave, sidx, lane);
                 MSNET_LDS_BARRIER();                    // b2: tile and group 0 are in LDS
-                // Next item: a continuation needs only its logical planes 2,3 (into the slots of this item's planes 0,1, dead
-                // after groups 2 / 5); a column start needs all four (0,1 into those slots, 2,3 in its own b1/b2 window).
-                Coord nx = coord_of(more ? it + 1 : it);
+                STAMP(wave, sidx, lane);
                 wrot = ncont ? rot ^ 1 : rot;
-                if (more) { if (ncont) issue_a(nx, 2, 0, PL); else { issue_a(nx, 0, 0, PL); issue_a(nx, 1, 0, HH); } }
+                if (more && !hoist) { if (ncont) issue_a(nx, 2, 0, PL); else { issue_a(nx, 0, 0, PL); issue_a(nx, 1, 0, HH); } }
                 MSNET_GROUP(0, bw1)
-                if (more) { if (ncont) issue_a(nx, 3, 0, PL); else { issue_a(nx, 1, HH, PL); issue_a(nx, 2, 0, PL); } }
+                if (more && !hoist) { if (ncont) issue_a(nx, 3, 0, PL); else { issue_a(nx, 1, HH, PL); issue_a(nx, 2, 0, PL); } }
                 MSNET_GROUP(1, bw2)
                 if (more && !ncont) issue_a(nx, 3, 0, PL);
                 MSNET_GROUP(2, bw0)                     // g_2 passed: this item's logical plane 0 is dead
@@ -453,6 +495,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 if (more) { if (ncont) write_a(3, HH, PL); else write_a(1, HH, PL); }
                 MSNET_GROUP(7, bw2)
                 early = more && !ncont;
+                cur = nxt; nxt.next();
             }
             return;
         }
@@ -464,9 +507,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         for (int it = 0; it < nitems; ++it) {
             const int k0 = it * 9;                      // 9 % 3 == 0: group k0+g always uses set g % 3
             const bool more = it + 1 < nitems;
-            if (wave == 4) STAMP(1, sidx, lane);
+            STAMP(wave, sidx, lane);
             MSNET_LDS_BARRIER();                        // b1: MFMA waves are done with the previous tile
-            if (wave == 4) STAMP(1, sidx, lane);
+            STAMP(wave, sidx, lane);
 #ifndef EXP_NO_A_STAGE
             if (!early) { write_a(0, 0, PL); write_a(1, 0, PL); }
             write_a(2, 0, PL); write_a(3, 0, PL);
@@ -474,12 +517,12 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #endif
             MSNET_WRITE_B(k0, bw0);
             MSNET_ISSUE_B(k0 + 3, bw0);
-            if (wave == 4) STAMP(1, sidx, lane);
+            STAMP(wave, sidx, lane);
             MSNET_LDS_BARRIER();                        // b2: tile and group 0 are in LDS
-            if (wave == 4) STAMP(1, sidx, lane);
+            STAMP(wave, sidx, lane);
             // group g+1 is copied to LDS (and group g+4 requested) while group g is multiplied; barrier g_g ends it.
             // The next tile is requested during groups 0-2; its planes 0 / 1 are copied as soon as they are dead.
-            Coord nx = coord_of(more ? it + 1 : it);
+            const Coord nx = coord_of(nxt);
 #ifndef EXP_NO_A_STAGE
             if (more) { issue_a(nx, 0, 0, PL); issue_a(nx, 1, 0, HH); }
 #endif
@@ -514,6 +557,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #endif
             MSNET_GROUP(7, bw2)
             early = more;
+            cur = nxt; nxt.next();
         }
 #undef MSNET_GROUP
 #undef MSNET_WRITE_B
@@ -589,6 +633,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     unsigned pbase[MB][NB];
     int plh[MB], plw[MB];
     bool pend_live = false;
+    float psc[NB], psh[NB], pamax = 0.f;                 // parked tile: per-channel scale / shift, running max magnitude
+#pragma unroll
+    for (int j = 0; j < NB; ++j) { psc[j] = 1.f; psh[j] = 0.f; }
     __amdgpu_buffer_rsrc_t pend_rs = make_rsrc(a.y, 0);
     auto park = [&](int n, int od0, int oh0, int ow0, int cg) {
         const size_t osample = (size_t)a.OD * a.OH * a.OW * a.Co * 4;
@@ -603,18 +650,13 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             for (int j = 0; j < NB; ++j) {
                 const int co = (cg * NB + j) * 32 + r;
                 pbase[i][j] = od < a.OD ? (unsigned)((((size_t)od * a.OH + ohb) * a.OW + owb) * a.Co + co) * 4u : 0xffffffffu;
-                const float sc = a.scale ? a.scale[co] : 1.f;
-                const float sh = a.shift ? a.shift[co] : 0.f;
+                psc[j] = a.scale ? a.scale[co] : 1.f;
+                psh[j] = a.shift ? a.shift[co] : 0.f;
+                // only the hi/lo combine happens here (the MFMA pipe idles while the tile is parked); scale, shift, ReLU and
+                // the range check ride with the drained stores, one element per K-step between the next tile's MFMAs
                 f32x16 t;
-                float amax = 0.f;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = (acc0[i][j][e] + acc1[i][j][e] * kLoInv) * sc + sh;
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    amax = fmaxf(amax, fabsf(v));
-                    t[e] = v;
-                }
-                flag_overflow(a.oflag, amax);
+                for (int e = 0; e < 16; ++e) t[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
                 pend[DRAIN ? i : 0][DRAIN ? j : 0] = t;
             }
         }
@@ -625,31 +667,67 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         if constexpr (DRAIN && q < PIECES) {
             constexpr int e = q % 16, j = (q / 16) % NB, i = q / (16 * NB);
             constexpr int c = (e & 3) + 8 * (e >> 2), lh = c / BW, lw = c % BW;
+#ifndef EXP_NO_SGB
+            {   // branch-free: with nothing parked the offset is out of range and the store is dropped
+                const bool ok = pend_live && pbase[i][j] != 0xffffffffu && lh < plh[i] && lw < plw[i];
+#else
             if (pend_live) {
                 const bool ok = pbase[i][j] != 0xffffffffu && lh < plh[i] && lw < plw[i];
+#endif
                 const unsigned o = ok ? pbase[i][j] + (unsigned)(lh * stride_h + lw * stride_w) * 4u : 0xffffffffu;
-                const float val = pend[i][j][e];        // (bit_cast applied to the vector element itself reads element 0)
+                float val = pend[i][j][e] * psc[j] + psh[j];      // (bit_cast applied to the vector element itself reads element 0)
+                if (a.relu) val = fmaxf(val, 0.f);
+                pamax = fmaxf(pamax, ok ? fabsf(val) : 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), pend_rs, o, 0, 0);
             }
         }
     };
 
+#ifdef EXP_BGLOB
+    // Experiment: the MFMA waves stream the B operand (weights) straight from L2 / L1 into a register ring BR steps deep
+    // instead of reading it from the LDS image the loaders maintain.
+    constexpr int NSB = 3 * KS;
+    constexpr int BR = (NB == 1 && KS == 2) ? 6 : 3;
+    constexpr int PFB = BR - 1;
+    static_assert(NSB % BR == 0, "B ring must tile the group");
+    half8 bgh[BR][NB], bgl[BR][NB];
+    auto frag_bg = [&](int s_, int slot, const u32x4* base) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const u32x4* p_ = base + ((s_ * NB + j) * 2) * 64;
+            bgh[slot][j] = __builtin_bit_cast(half8, p_[0]);
+            bgl[slot][j] = __builtin_bit_cast(half8, p_[64]);
+        }
+    };
+    auto wbase_of = [&](int it_) {                      // (experiment only: decodes with divisions)
+        const unsigned t_ = lb + (unsigned)((it_ < nitems ? it_ : nitems - 1) / per_unit) * G;
+        const int ch_ = SLIDE ? 0 : (it_ < nitems ? it_ : nitems - 1) % nchunks;
+        return wg + (size_t)(((int)(t_ % ncg) * nchunks + ch_) * 9) * PG + lane;
+    };
+    {
+        const u32x4* w0 = wbase_of(0);
+#pragma unroll
+        for (int q = 0; q < PFB; ++q) frag_bg(q, q, w0);
+    }
+#endif
     int sidx = 0;
+    TileCtr ctr = ctr0;
     for (int it = 0; it < nitems; ++it) {
         int n, od0, oh0, ow0, chunk, cg;
-        decode_g(it, n, od0, oh0, ow0, chunk, cg);
-        if (continues(it)) rot ^= 1;
-        if (wave == 0) STAMP(0, sidx, lane);
+        coords(ctr, n, od0, oh0, ow0, chunk, cg);
+        if (SLIDE && ctr.pos != 0) rot ^= 1;             // next tile of the same column
+        ctr.next();
+        STAMP(wave, sidx, lane);
         MSNET_LDS_BARRIER();                            // b1
-        if (wave == 0) STAMP(0, sidx, lane);
+        STAMP(wave, sidx, lane);
         if (pending) {
             if (DRAIN && !a.res) park(pn, pod0, poh0, pow0, pcg);
             else epilogue(pn, pod0, poh0, pow0, pcg);
             pending = false;
         }
-        if (wave == 0) STAMP(0, sidx, lane);
+        STAMP(wave, sidx, lane);
         MSNET_LDS_BARRIER();                            // b2
-        if (wave == 0) STAMP(0, sidx, lane);
+        STAMP(wave, sidx, lane);
         if (chunk == 0) {
 #pragma unroll
             for (int i = 0; i < MB; ++i)
@@ -704,27 +782,52 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #pragma unroll
         for (int q = 0; q < PF; ++q) frag_a(q, q, goff_next);
         // one weight group; `drain(s)` runs behind the MFMAs of step s (s as an integral_constant)
+#ifdef EXP_BGLOB
+        const u32x4* const wcur = wbase_of(it);
+        const u32x4* const wnxt = wbase_of(it + 1);
+#endif
         auto do_group = [&](int g, auto drain) {
             const unsigned char* bb = lds_b + (RESB ? g : ((gg0 + g) & 1)) * GB + lane * 16;
 #pragma unroll
             for (int i = 0; i < MB; ++i) { goff[i] = goff_next[i]; goff_next[i] = grp_off(g + 1, i); }   // (kd, kh) rows, in voxels
+#ifdef EXP_BGLOB
+            const u32x4* const bg = wcur + (size_t)g * PG;
+            const u32x4* const bgn = g < 8 ? bg + PG : wnxt;
+            (void)bb;
+#else
 #pragma unroll
             for (int q = 0; q < PF; ++q) frag_b(q, q, bb);
+#endif
             static_for<NS>([&](auto sc_) {
                 constexpr int s = decltype(sc_)::value;
 #ifndef EXP_NO_FRAG
+#ifdef EXP_BGLOB
+                if (s + PF < NS) frag_a(s + PF, (s + PF) % R, goff);
+                else if (g < 8) frag_a(s + PF - NS, (s + PF) % R, goff_next);
+                if (s + PFB < NS) frag_bg(s + PFB, (s + PFB) % BR, bg);
+                else frag_bg(s + PFB - NS, (s + PFB) % BR, bgn);
+#else
                 if (s + PF < NS) { frag_a(s + PF, (s + PF) % R, goff); frag_b(s + PF, (s + PF) % R, bb); }
                 else if (g < 8) frag_a(s + PF - NS, (s + PF) % R, goff_next);
 #endif
+#endif
+#ifdef EXP_NO_SGB
                 __builtin_amdgcn_sched_barrier(0);
+#endif
 #ifndef EXP_NO_MFMA
 #pragma unroll
                 for (int i = 0; i < MB; ++i)
 #pragma unroll
                     for (int j = 0; j < NB; ++j) {
+#ifdef EXP_BGLOB
+                        acc0[i][j] = mfma16(ah[s % R][i], bgh[s % BR][j], acc0[i][j]);
+                        acc1[i][j] = mfma16(al[s % R][i], bgh[s % BR][j], acc1[i][j]);
+                        acc1[i][j] = mfma16(ah[s % R][i], bgl[s % BR][j], acc1[i][j]);
+#else
                         acc0[i][j] = mfma16(ah[s % R][i], bh_[s % R][j], acc0[i][j]);
                         acc1[i][j] = mfma16(al[s % R][i], bh_[s % R][j], acc1[i][j]);
                         acc1[i][j] = mfma16(ah[s % R][i], bl[s % R][j], acc1[i][j]);
+#endif
                     }
 #else
 #pragma unroll
@@ -733,13 +836,26 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 for (int j = 0; j < NB; ++j) asm volatile("" ::"v"(bh_[s % R][j]), "v"(bl[s % R][j]));
 #endif
                 drain(sc_);
+#ifndef EXP_NO_SGB
+                {   // Interleave: the wave is in-order, so everything placed after a step's last MFMA delays the next step's
+                    // first one.  One LDS read and two VALU behind each MFMA instead (an MFMA leaves ~24 issue cycles free).
+                    constexpr int NM_ = 3 * MB * NB, NRD_ = 2 * MB + 2 * NB;
+#pragma unroll
+                    for (int m = 0; m < NM_; ++m) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        if (m < NRD_) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                        if (m == NM_ - 2) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                    }
+                }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             });
 #ifndef EXP_NO_GROUP_BARRIER
             if (!RESB && g < 8) {
-                if (wave == 0) STAMP(0, sidx, lane);
+                STAMP(wave, sidx, lane);
                 MSNET_LDS_BARRIER();                    // g_g
-                if (wave == 0) STAMP(0, sidx, lane);
+                STAMP(wave, sidx, lane);
             }
 #endif
         };
@@ -748,6 +864,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 constexpr int g = decltype(gc)::value;
                 do_group(g, [&](auto sc_) { drain_piece(std::integral_constant<int, g * NS + decltype(sc_)::value>{}); });
             });
+            if (pend_live) flag_overflow(a.oflag, pamax);
+            pamax = 0.f;
             pend_live = false;
         } else {
 #pragma unroll 1                                 // (expanding the nine groups here too was measured: Co=64 spills, stride 2 gains 1 %)
@@ -1548,7 +1666,7 @@ using namespace msnet;
 
 #ifdef EXP_STAMP
 extern "C" int msnet_debug_read_stamps(unsigned long long* host) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 512) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 1024) == hipSuccess ? 0 : 1;
 }
 #endif
 

@@ -7,10 +7,10 @@ from msnets_amd import _lib
 name = sys.argv[1] if len(sys.argv) > 1 else "s1_32_32"
 T.run(name, "split-fp16", reps=1)
 lib = ctypes.CDLL(os.environ["MSNET_HIP_LIB"])
-buf = (ctypes.c_ulonglong * 512)()
+buf = (ctypes.c_ulonglong * 1024)()
 assert lib.msnet_debug_read_stamps(buf) == 0
-for role, nm in ((0, "MFMA wave0"), (1, "loader wave4")):
-    v = [buf[role * 256 + i] for i in range(256)]
-    t0 = v[0]
-    print(nm, "deltas (cycles) between consecutive stamps, first 70:")
-    print(" ".join(str(v[i + 1] - v[i]) for i in range(70)))
+t0 = min(buf[w * 128] for w in range(8) if buf[w * 128])
+for w in range(8):
+    v = [buf[w * 128 + i] for i in range(128)]
+    print("wave %d (%s): stamp times relative to the first stamp of the block, stamps 40..83:" % (w, "MFMA" if w < 4 else "loader"))
+    print(" ".join(str(v[i] - t0) for i in range(40, 84)))
