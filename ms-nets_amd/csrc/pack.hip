@@ -36,13 +36,30 @@ __global__ __launch_bounds__(256) void ncs_to_nsc_kernel(const float* __restrict
     const int cnt = (int)((S - s0 < 256) ? (S - s0) : 256);
     const float* sp = src + (size_t)n * C * S + s0;
     float amax = 0.f;                                      // the module input feeds a split-fp16 layer: fp16 range guard
-    for (int c = 0; c < C; ++c)
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {                           // eight independent plane loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = tid < cnt ? sp[(size_t)(c + u) * S + tid] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { amax = fmaxf(amax, fabsf(v[u])); tile[(c + u) * LS + tid] = v[u]; }
+    }
+    for (; c < C; ++c)
         if (tid < cnt) { const float v = sp[(size_t)c * S + tid]; amax = fmaxf(amax, fabsf(v)); tile[c * LS + tid] = v; }
     if (oflag && !(amax < 65504.f)) atomicOr(oflag, 1u);
     __syncthreads();
     float* dp = dst + ((size_t)n * S + s0) * C;
     const int total = cnt * C;
-    for (int k = tid; k < total; k += 256) dp[k] = tile[(k % C) * LS + k / C];
+    if ((C & (C - 1)) == 0 && C >= 4) {                    // power-of-two channel counts: shifts instead of divisions, 16-byte stores
+        const int sh = __builtin_ctz(C), q = C >> 2;       // q float4 per voxel
+        for (int k4 = tid; k4 < (total >> 2); k4 += 256) {
+            const int vox = k4 >> (sh - 2), c4 = (k4 & (q - 1)) << 2;
+            const f32x4 o = {tile[c4 * LS + vox], tile[(c4 + 1) * LS + vox], tile[(c4 + 2) * LS + vox], tile[(c4 + 3) * LS + vox]};
+            reinterpret_cast<f32x4*>(dp)[k4] = o;
+        }
+    } else {
+        for (int k = tid; k < total; k += 256) dp[k] = tile[(k % C) * LS + k / C];
+    }
 }
 
 __global__ __launch_bounds__(256) void nsc_to_ncs_kernel(const float* __restrict__ src, float* __restrict__ dst,
