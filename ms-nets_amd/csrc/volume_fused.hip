@@ -558,7 +558,7 @@ bool volume_fast_supported(const msnet_volume_params& p, int Hb, int Wb, int nd)
     if (p.border_h < 6 || p.border_w < 6) return false;    // every window of a cropped pixel is inside the image
     if (nd % 8 != 0 || nd > 96) return false;
     if ((size_t)nd * (Hb - 2 * p.border_h) * (Wb - 2 * p.border_w) * 4 > 0xfffffff0u) return false;   // one channel per buffer descriptor
-    if (Wb + 8 > 1200) return false;                        // LDS band of the Sobel-SAD kernel (32 rows x (Wb + 8) floats)
+    if (Wb + 8 > 2500) return false;                        // LDS band of the Sobel-SAD kernel (16 rows x (Wb + 8) floats)
     if (cdiv(Hb - 2 * p.border_h, kBandRMin) > kMaxBands) return false;   // band table of the Sobel-SAD kernels
     if (Hb > 8000) return false;                            // exact vertical sums: Hb * 2040 < 2^24 (sadsob_bandsum_kernel)
     return true;
@@ -626,7 +626,9 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
             return 0;
         };
         int rc = 0;
-        if (band_cfg == 1) rc = launch(std::integral_constant<int, 27>{}, std::integral_constant<int, 256>{});
+        const bool wide = (size_t)(27 + kSW) * LS * sizeof(float) > 160 * 1024;     // full-resolution KITTI widths: 16-row bands
+        if (wide) rc = launch(std::integral_constant<int, 11>{}, std::integral_constant<int, 256>{});
+        else if (band_cfg == 1) rc = launch(std::integral_constant<int, 27>{}, std::integral_constant<int, 256>{});
         else if (band_cfg == 2) rc = launch(std::integral_constant<int, 11>{}, std::integral_constant<int, 256>{});
         else if (band_cfg == 3) rc = launch(std::integral_constant<int, 59>{}, std::integral_constant<int, 512>{});
         else rc = launch(std::integral_constant<int, 27>{}, std::integral_constant<int, 512>{});

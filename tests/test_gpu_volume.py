@@ -99,7 +99,8 @@ def test_fused_volume_build(gpu, H, W, nd, seed, kind):
 
 
 @pytest.mark.parametrize("H,W,nd,seed,kind", [(68, 100, 16, 0, "texture"), (40, 150, 32, 3, "extreme"), (57, 93, 8, 2, "flat"),
-                                              (84, 212, 48, 8, "random"), (292, 500, 96, 6, "texture")])
+                                              (84, 212, 48, 8, "random"), (292, 500, 96, 6, "texture"),
+                                              (45, 1300, 24, 9, "random")])     # wider than a 32-row LDS band: 16-row bands
 def test_fast_and_generic_volume_paths_agree(gpu, monkeypatch, H, W, nd, seed, kind):
     """msnet_build_volume has a register-resident fast path for the reference's own windows (volume_fused.hip) and the
     run-time-window kernels (volume.hip, forced here with MSNET_VOLUME_GENERIC=1).  Cost channels must be bit-identical
