@@ -632,6 +632,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     f32x16 pend[DRAIN ? MB : 1][DRAIN ? NB : 1];
     unsigned pbase[MB][NB];
     int plh[MB], plw[MB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i) { plh[i] = 0; plw[i] = 0; }
     bool pend_live = false;
     float psc[NB], psh[NB], pamax = 0.f;                 // parked tile: per-channel scale / shift, running max magnitude
 #pragma unroll
@@ -646,6 +648,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             const int bw_ = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
             const int od = od0 + bd, ohb = oh0 + bh * BH, owb = ow0 + bw_ * BW + 4 * hh;
             plh[i] = a.OH - ohb; plw[i] = a.OW - owb;
+            // one compare per drained store: rows of this M-block beyond the tensor (or a whole M-block beyond its depth) get
+            // a column limit of zero (BW == 32: an M-block is one row, lh is always 0)
+            if (od >= a.OD || plh[i] <= 0) plw[i] = 0;
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 const int co = (cg * NB + j) * 32 + r;
@@ -668,8 +673,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             constexpr int e = q % 16, j = (q / 16) % NB, i = q / (16 * NB);
             constexpr int c = (e & 3) + 8 * (e >> 2), lh = c / BW, lw = c % BW;
 #ifndef EXP_NO_SGB
-            {   // branch-free: with nothing parked the offset is out of range and the store is dropped
-                const bool ok = pend_live && pbase[i][j] != 0xffffffffu && lh < plh[i] && lw < plw[i];
+            {   // branch-free: with nothing parked (plw == 0) the offset is out of range and the store is dropped
+                static_assert(BW == 32 || !DRAIN, "drained stores assume one-row M-blocks");
+                const bool ok = lw < plw[i];
 #else
             if (pend_live) {
                 const bool ok = pbase[i][j] != 0xffffffffu && lh < plh[i] && lw < plw[i];
@@ -867,6 +873,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             if (pend_live) flag_overflow(a.oflag, pamax);
             pamax = 0.f;
             pend_live = false;
+#pragma unroll
+            for (int i = 0; i < MB; ++i) plw[i] = 0;
         } else {
 #pragma unroll 1                                 // (expanding the nine groups here too was measured: Co=64 spills, stride 2 gains 1 %)
             for (int g = 0; g < 9; ++g) do_group(g, [](auto) {});
