@@ -158,7 +158,13 @@ def measure_peaks(dev):
     def mfma():
         flops[0] = lib.msnet_peak_mfma_f16(_lib.ptr(dst), 40000, _lib.stream_ptr())
     t_mfma = timed(mfma, 3)
-    return {"hbm_copy_GBs": 2.0 * n / t_copy / 1e6, "mfma_f16_TFLOPs": flops[0] / t_mfma / 1e9}
+    f32 = flops[0]
+
+    def mfma16():
+        flops[0] = lib.msnet_peak_mfma_f16_16x16(_lib.ptr(dst), 40000, _lib.stream_ptr())
+    t_mfma16 = timed(mfma16, 3)
+    return {"hbm_copy_GBs": 2.0 * n / t_copy / 1e6, "mfma_f16_TFLOPs": f32 / t_mfma / 1e9,
+            "mfma_f16_16x16x32_TFLOPs": flops[0] / t_mfma16 / 1e9}
 
 
 def main():

@@ -59,6 +59,7 @@ int msnet_set_exact_tails(int on);
  * (0 on error); `scratch` is any device buffer of >= 1 MiB.  Time both with events on `stream`. */
 int    msnet_peak_copy(const void* src, void* dst, size_t bytes, msnet_stream_t stream);
 double msnet_peak_mfma_f16(void* scratch, int iters, msnet_stream_t stream);
+double msnet_peak_mfma_f16_16x16(void* scratch, int iters, msnet_stream_t stream);   /* same, v_mfma_f32_16x16x32_f16 */
 
 /* ---- matchers: replaces src/cpp/matchers/matchers.cpp:565-580 (libmatchers) ----------------- */
 /* census(left,right,ndisp,wsize) matchers.cpp:232-353.  l,r: u8[H][W]; out: f32[H][W][ndisp];

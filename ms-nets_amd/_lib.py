@@ -29,6 +29,7 @@ SIGNATURES = {
     "msnet_set_exact_tails": (c_int, [c_int]),
     "msnet_peak_copy": (c_int, [P, P, c_size_t, P]),
     "msnet_peak_mfma_f16": (ctypes.c_double, [P, c_int, P]),
+    "msnet_peak_mfma_f16_16x16": (ctypes.c_double, [P, c_int, P]),
     "msnet_census": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "msnet_census_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "msnet_ncc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
