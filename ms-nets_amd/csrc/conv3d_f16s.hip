@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             return;
         }
         bool early = false;                             // planes 0,1 of this item already copied during the previous one
-        int sidx = 0;
+        [[maybe_unused]] int sidx = 0;
         // The loader shares each SIMD with an MFMA wave and runs ~3x slower than alone, so its per-item work (28 loads,
         // 28 split+copy, 27 weight pieces) is spread evenly over the nine group slots instead of bunched at the barriers.
         constexpr int H0 = (PL + 2) / 3, H1 = (2 * PL + 2) / 3, HH = (PL + 1) / 2;
@@ -716,7 +716,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         for (int q = 0; q < PFB; ++q) frag_bg(q, q, w0);
     }
 #endif
-    int sidx = 0;
+    [[maybe_unused]] int sidx = 0;
     TileCtr ctr = ctr0;
     for (int it = 0; it < nitems; ++it) {
         int n, od0, oh0, ow0, chunk, cg;
@@ -1309,7 +1309,7 @@ __global__ void pack_weight_c8_f16s_kernel(const float* __restrict__ w, _Float16
 }
 
 template <int NB>
-__global__ __launch_bounds__(256, 2) void conv3d_c8_f16s_kernel(ConvArgs a) {
+__global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(ConvArgs a) {    // (Co = 64: 128 accumulator registers, one workgroup per CU)
     constexpr int TD = 2, TH = 4, TW = 32, ID = TD + 2, IH = TH + 2, IW = TW + 2, NPOS = ID * IH * IW;
     constexpr int NSLOT = NPOS * 2, NL = (NSLOT + 255) / 256;           // float4 (channel quads) per thread per tile
     constexpr int WB = 14 * NB * 2 * 1024;
@@ -1326,28 +1326,35 @@ __global__ __launch_bounds__(256, 2) void conv3d_c8_f16s_kernel(ConvArgs a) {
         u32x4* dst = reinterpret_cast<u32x4*>(lds_b);
         for (int k = tid; k < WB / 16; k += 256) dst[k] = src[k];
     }
-    auto decode = [&](int it, int& n, int& d0, int& h0, int& w0) {
-        unsigned t = lb + (unsigned)it * G;
-        w0 = (t % a.ntw) * TW; t /= a.ntw;
-        h0 = (t % a.nth) * TH; t /= a.nth;
-        d0 = (t % a.ntd) * TD;
-        n = t / a.ntd;
-    };
-    // loader role: slot = u*256 + tid -> (pos = slot >> 1, quad = slot & 1)
+    // loader role: slot = u*256 + tid -> (pos = slot >> 1, quad = slot & 1).  Per-slot constants (position in the tile, byte
+    // offset from the tile origin) are computed once; an interior tile costs one add + one buffer load per slot.
     const size_t isample = (size_t)a.D * a.H * a.W * 8 * 4;
     f32x4 av[NL];
-    auto issue_a = [&](int it) {
-        int n, d0, h0, w0;
-        decode(it, n, d0, h0, w0);
-        const auto rsrc = make_rsrc(a.x + (size_t)n * (isample / 4), isample);
+    unsigned rel_[NL];                                   // byte offset of the slot from the tile's input origin (d0-1, h0-1, w0-1)
+    int dhw_[NL];                                        // (id << 16) | (ih << 8) | iw, or -1 past the tile's end
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+        const int slot = u * 256 + tid, pos = slot >> 1, q = slot & 1;
+        const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
+        rel_[u] = (unsigned)((((id * a.H + ih) * a.W + iw) * 8 + q * 4) * 4);
+        dhw_[u] = slot < NSLOT ? ((id << 16) | (ih << 8) | iw) : -1;
+    }
+    TileCtr ctr, nxt;                                    // current item / the one being fetched
+    ctr.init(lb, G, 1, a.ntw, a.nth, a.ntd, 1);
+    nxt = ctr;
+    auto issue_a = [&](const TileCtr& c) {
+        const int d0 = c.td * TD, h0 = c.th * TH, w0 = c.tw * TW;
+        const auto rsrc = make_rsrc(a.x + (size_t)c.n * (isample / 4), isample);
+        const unsigned base = (unsigned)(((((long)(d0 - 1) * a.H + (h0 - 1)) * a.W + (w0 - 1)) * 8) * 4);   // may wrap; in-range slots bring it back
+        const bool interior = d0 >= 1 && d0 - 1 + ID <= a.D && h0 >= 1 && h0 - 1 + IH <= a.H && w0 >= 1 && w0 - 1 + IW <= a.W;
 #pragma unroll
         for (int u = 0; u < NL; ++u) {
-            const int slot = u * 256 + tid, pos = slot >> 1, q = slot & 1;
-            const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
-            const int gd = d0 - 1 + id, gh = h0 - 1 + ih, gw = w0 - 1 + iw;
-            const bool ok = slot < NSLOT && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
-            const unsigned voff = ok ? (unsigned)((((size_t)gd * a.H + gh) * a.W + gw) * 8 + q * 4) * 4u : 0xffffffffu;
-            av[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+            bool ok = dhw_[u] >= 0;
+            if (!interior) {
+                const int gd = d0 - 1 + (dhw_[u] >> 16), gh = h0 - 1 + ((dhw_[u] >> 8) & 255), gw = w0 - 1 + (dhw_[u] & 255);
+                ok = ok && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+            }
+            av[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? base + rel_[u] : 0xffffffffu, 0, 0));
         }
     };
     auto write_a = [&]() {
@@ -1369,14 +1376,15 @@ __global__ __launch_bounds__(256, 2) void conv3d_c8_f16s_kernel(ConvArgs a) {
     for (int i = 0; i < 2; ++i) vox0[i] = ((wave >> 1) * IH + (wave & 1) * 2 + i) * IW + r;
     const size_t osample = (size_t)a.OD * a.OH * a.OW * a.Co * 4;
 
-    issue_a(0);
+    issue_a(nxt);
     for (int it = 0; it < nitems; ++it) {
-        int n, d0, h0, w0;
-        decode(it, n, d0, h0, w0);
+        const int n = ctr.n, d0 = ctr.td * TD, h0 = ctr.th * TH, w0 = ctr.tw * TW;
+        ctr.next();
+        nxt.next();
         __syncthreads();                                // previous tile fully consumed (and the weights are in LDS)
         write_a();
         __syncthreads();
-        if (it + 1 < nitems) issue_a(it + 1);           // in flight during the MFMAs and the epilogue
+        if (it + 1 < nitems) issue_a(nxt);              // in flight during the MFMAs and the epilogue
         f32x16 acc0[2][NB], acc1[2][NB];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -1428,7 +1436,12 @@ __global__ __launch_bounds__(256, 2) void conv3d_c8_f16s_kernel(ConvArgs a) {
                 f32x16 v, rv;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) v[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
-                residual_prefetch<32>(rv, rs_res, off, 0, a.Co * 4, valid);
+                if (a.res) {
+                    residual_prefetch<32>(rv, rs_res, off, 0, a.Co * 4, valid);
+                } else {                                // (the first layer has no residual: no point in 16 loads that return zero)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) rv[e] = 0.f;
+                }
                 epilogue_store<32>(v, rv, sc, sh, rs_y, off, 0, a.Co * 4, a.relu, valid, a.oflag);
             }
         }
