@@ -951,6 +951,7 @@ extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, in
     if (!(generic && generic[0] == '1') && volume_fast_supported(p, Hb, Wb, ndisp))
         return volume_fast_launch(l, r, Hb, Wb, ndisp, p, workspace, out, s);
     const size_t img = (size_t)Hb * Wb;
+    LaunchScope whole("vol_build", s, 0, 4.0 * 8.0 * ndisp * (double)Hc * Wc + 2.0 * img);     // the whole build (bench.py's roofline_volume)
     float* integ = (float*)workspace;
     float* sobl = integ + (size_t)ndisp * (Hb + 1) * (Wb + 1);
     float* sobr = sobl + img;
@@ -969,19 +970,19 @@ extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, in
     a.censw = p.censw; a.nccw = p.nccw; a.sadw = p.sadw; a.sobelw = p.sobelw; a.nwords = nwords;
 
     {
-        LaunchScope ls("vol_prep", s, 0, 2.0 * img * (1 + 4.0 * nwords) + 48.0 * img);
+        LaunchScope ls("volk_prep", s, 0, 2.0 * img * (1 + 4.0 * nwords) + 48.0 * img);
         hipLaunchKernelGGL(volume_prep_kernel, dim3(cdiv(Wb, 64), Hb, 5), dim3(64), 0, s, a, sobl, sobr);
     }
     {
-        LaunchScope ls("vol_sadsob_v", s, 0, 4.0 * ndisp * (double)(Hb + 1) * (Wb + 1));
+        LaunchScope ls("volk_sadsob_v", s, 0, 4.0 * ndisp * (double)(Hb + 1) * (Wb + 1));
         hipLaunchKernelGGL(sadsob_vertical_kernel, dim3(cdiv(Wb + 1, 64), ndisp), dim3(64), 0, s, sobl, sobr, integ, Hb, Wb, ndisp);
     }
     {
-        LaunchScope ls("vol_sadsob_h", s, 0, 8.0 * ndisp * (double)(Hb + 1) * (Wb + 1));
+        LaunchScope ls("volk_sadsob_h", s, 0, 8.0 * ndisp * (double)(Hb + 1) * (Wb + 1));
         hipLaunchKernelGGL(sadsob_horizontal_kernel, dim3(cdiv(Hb + 1, 64), ndisp), dim3(64), 0, s, integ, Hb, Wb, ndisp);
     }
     {
-        LaunchScope ls("vol_features", s, 0, 4.0 * 8.0 * ndisp * (double)Hc * Wc);
+        LaunchScope ls("volk_features", s, 0, 4.0 * 8.0 * ndisp * (double)Hc * Wc);
         const dim3 gf(cdiv(Wc, 64), cdiv(Hc, 4), 4);
         if (p.censw == 11 && p.nccw == 3 && p.sobelw == 5 && p.sadw == 5)
             hipLaunchKernelGGL((features_all_kernel<11, 3, 5, 5>), gf, dim3(256), 0, s, a);

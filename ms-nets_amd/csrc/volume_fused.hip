@@ -20,6 +20,7 @@
 // of the reference's result.
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -523,35 +524,19 @@ template <int ND> constexpr size_t features_smem_bytes() {
     return (m0 > m1 ? (m0 > m3 ? m0 : m3) : (m1 > m3 ? m1 : m3)) + 16;
 }
 
-// ZSAD keeps 96 costs + the 25 left terms + the 5x5 sliding window in registers (~210): its own kernel at two waves per
-// SIMD.  The other three matchers need ~120 registers and run four waves per SIMD (blockIdx.z: NCC, census, Sobel-SAD).
+// One kernel for the four matchers at three waves per SIMD (blockIdx.z + zbase: ZSAD, NCC, census, Sobel-SAD): ZSAD keeps 96
+// costs + 25 left terms + a 5x5 sliding window in registers (155 with the per-step sched_barrier), the others ~120; the VALU-bound
+// ZSAD waves share the CUs with the store-bound ones (135 us vs 84 + 51 us as two launches at 4 / 2 waves per SIMD)
 template <int ND>
-__global__ __launch_bounds__(256, 2) void features_zsad_kernel(FastArgs a) {
+__global__ __launch_bounds__(256, 3) void features4_kernel(FastArgs a, int zbase) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[features_smem_bytes<ND>()];
-    features_px<3, ND>(a, smem);
-}
-// all four matchers in one launch at three waves per SIMD (blockIdx.z: ZSAD, NCC, census, Sobel-SAD): the VALU-bound ZSAD
-// waves share the CUs with the store-bound ones
-template <int ND>
-__global__ __launch_bounds__(256, 3) void features4_kernel(FastArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[features_smem_bytes<ND>()];
-    switch (blockIdx.z) {
+    switch (blockIdx.z + zbase) {
     case 0: features_px<3, ND>(a, smem); break;
     case 1: features_px<1, ND>(a, smem); break;
     case 2: features_px<0, ND>(a, smem); break;
     default: features_px<2, ND>(a, smem); break;
     }
 }
-template <int ND>
-__global__ __launch_bounds__(256, 4) void features_kernel(FastArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[features_smem_bytes<ND>()];
-    switch (blockIdx.z) {
-    case 0: features_px<1, ND>(a, smem); break;
-    case 1: features_px<0, ND>(a, smem); break;
-    default: features_px<2, ND>(a, smem); break;
-    }
-}
-
 // ------------------------------------------------------------------------------------------------ host
 bool volume_fast_supported(const msnet_volume_params& p, int Hb, int Wb, int nd) {
     if (p.censw != kCW || p.nccw != kNW || p.sobelw != kSW || p.sadw != kZW) return false;
@@ -577,6 +562,27 @@ size_t volume_fast_workspace_bytes(int Hb, int Wb, int nd) {
     return img * (2 * 16 + 2 * 16 + 4 * 4) + (size_t)nd * cdiv(Hc, kBandRMin) * band_ls(Wb) * sizeof(float) + 256;
 }
 
+// Second stream of the build: the Sobel-SAD kernels (one wave per workgroup busy most of the time, LDS-capacity-bound) run
+// beside the feature kernel of the other three matchers (VALU- and store-bound) instead of in front of it.  One helper
+// stream and two events per device, created on first use; fork / join are ordinary event waits, so the build stays
+// asynchronous on the caller's stream and capturable.
+struct VolAux { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false, tried = false; };
+static VolAux& vol_aux() {
+    static VolAux aux[32];
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
+    VolAux& x = aux[dev];
+    if (!x.tried) {
+        x.tried = true;
+        x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
+               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+    }
+    return x;
+}
+
 int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int nd, const msnet_volume_params& p, void* workspace,
                        float* out, hipStream_t s) {
     const size_t img = (size_t)Hb * Wb;
@@ -594,22 +600,26 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
     a.Hc = Hb - 2 * p.border_h; a.Wc = Wb - 2 * p.border_w;
     const size_t plane = (size_t)a.Hc * a.Wc;
     const dim3 gpix(cdiv(a.Wc, 64), cdiv(a.Hc, 4), 1);
+    static const int band_skip = [] { const char* e = getenv("MSNET_BAND_SKIP"); return e ? atoi(e) : 0; }();     // diagnostic: skip phases
+    static const int band_cfg = [] { const char* e = getenv("MSNET_BAND_CFG"); return e ? atoi(e) : 0; }();       // tuning: band height / threads
+    static const bool want_overlap = [] { const char* e = getenv("MSNET_VOL_STREAMS"); return !(e && e[0] == '0'); }();
+    VolAux& aux = vol_aux();
+    const bool overlap = want_overlap && aux.ok;
+    hipStream_t sb = overlap ? aux.s : s;                  // stream of the Sobel-SAD kernels
+
+    LaunchScope whole("vol_build", s, 0, 4.0 * 8.0 * nd * (double)plane + 2.0 * img);     // the whole build on the caller's stream
     {
-        LaunchScope ls("vol_prep", s, 0, 2.0 * img + 72.0 * img);
+        LaunchScope ls("volk_prep", s, 0, 2.0 * img + 72.0 * img);
         hipLaunchKernelGGL(vprep_kernel, dim3(cdiv(Wb, 64), cdiv(Hb, 4), 3), dim3(256), 0, s, a);
     }
-    static const bool merged = [] { const char* e = getenv("MSNET_VOL_MERGED"); return !(e && e[0] == '0'); }();   // default: one launch for the four matchers
-    if (!merged) {
-        LaunchScope ls("vol_zsad", s, 0, 4.0 * 2.0 * nd * (double)plane);
-        if (nd <= 32) hipLaunchKernelGGL(features_zsad_kernel<32>, gpix, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(features_zsad_kernel<96>, gpix, dim3(256), 0, s, a);
+    if (overlap) {
+        if (hipEventRecord(aux.fork, s) != hipSuccess || hipStreamWaitEvent(aux.s, aux.fork, 0) != hipSuccess)
+            return fail("msnet_build_volume: stream fork failed");
     }
     {
         const int LS = band_ls(Wb);
         float* park = out + (size_t)6 * nd * plane;         // channel 6 = likelihood of the Sobel-SAD cost
-        static const int band_skip = [] { const char* e = getenv("MSNET_BAND_SKIP"); return e ? atoi(e) : 0; }();     // diagnostic: skip phases
-        static const int band_cfg = [] { const char* e = getenv("MSNET_BAND_CFG"); return e ? atoi(e) : 0; }();       // tuning: band height / threads
-        LaunchScope ls("vol_sadsob", s, 0, 4.0 * nd * (double)plane);
+        LaunchScope ls("volk_sadsob", sb, 0, 4.0 * nd * (double)plane);
         auto launch = [&](auto rc, auto ntc) -> int {
             constexpr int R = decltype(rc)::value, NT = decltype(ntc)::value;
             const int nbands = cdiv(a.Hc, R);
@@ -621,8 +631,8 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
                 (void)hipFuncSetAttribute((const void*)sadsob_band_kernel<R, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 attr_set = true;
             }
-            hipLaunchKernelGGL(sadsob_bandsum_kernel<R>, dim3(cdiv(LS, 256), nbands, nd), dim3(256), 0, s, a, ck, LS, nbands);
-            hipLaunchKernelGGL((sadsob_band_kernel<R, NT>), dim3(nd * nbands), dim3(NT), lds, s, a, ck, park, LS, nbands, band_skip);
+            hipLaunchKernelGGL(sadsob_bandsum_kernel<R>, dim3(cdiv(LS, 256), nbands, nd), dim3(256), 0, sb, a, ck, LS, nbands);
+            hipLaunchKernelGGL((sadsob_band_kernel<R, NT>), dim3(nd * nbands), dim3(NT), lds, sb, a, ck, park, LS, nbands, band_skip);
             return 0;
         };
         int rc = 0;
@@ -634,16 +644,23 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
         else rc = launch(std::integral_constant<int, 27>{}, std::integral_constant<int, 512>{});
         if (rc) return rc;
     }
-    if (merged) {
-        LaunchScope ls("vol_features", s, 0, 4.0 * 8.0 * nd * (double)plane);
-        const dim3 g(gpix.x, gpix.y, 4);
-        if (nd <= 32) hipLaunchKernelGGL(features4_kernel<32>, g, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(features4_kernel<96>, g, dim3(256), 0, s, a);
+    if (overlap && hipEventRecord(aux.join, aux.s) != hipSuccess) return fail("msnet_build_volume: stream join failed");
+    auto features = [&](int zbase, int nz) {
+        const dim3 g(gpix.x, gpix.y, nz);
+        if (nd <= 32) hipLaunchKernelGGL(features4_kernel<32>, g, dim3(256), 0, s, a, zbase);
+        else hipLaunchKernelGGL(features4_kernel<96>, g, dim3(256), 0, s, a, zbase);
+    };
+    if (overlap) {
+        {
+            LaunchScope ls("volk_features", s, 0, 4.0 * 6.0 * nd * (double)plane);
+            features(0, 3);                                 // ZSAD, NCC, census: no dependence on the Sobel-SAD stream
+        }
+        if (hipStreamWaitEvent(s, aux.join, 0) != hipSuccess) return fail("msnet_build_volume: stream join failed");
+        LaunchScope ls("volk_features_sobel", s, 0, 4.0 * 2.0 * nd * (double)plane);
+        features(3, 1);
     } else {
-        LaunchScope ls("vol_features", s, 0, 4.0 * 6.0 * nd * (double)plane);
-        const dim3 g(gpix.x, gpix.y, 3);
-        if (nd <= 32) hipLaunchKernelGGL(features_kernel<32>, g, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(features_kernel<96>, g, dim3(256), 0, s, a);
+        LaunchScope ls("volk_features", s, 0, 4.0 * 8.0 * nd * (double)plane);
+        features(0, 4);
     }
     return check_launch("msnet_build_volume");
 }
