@@ -187,6 +187,13 @@ int msnet_deconv3d_cout1(const float* x, const float* w, float bias_host, float*
 int msnet_trilinear_softargmin(const float* cost, float* disp, int N, int d, int h, int w, int D, int H,
                                int W, msnet_stream_t stream);
 
+/* ---- driver-side metric ------------------------------------------------------------------------ */
+/* get_epe_rate(disp, prediction, max_disp, threshold), main_msnet.py:708-713, on the device: over the pixels with
+ * 0.001 <= gt <= max_disp, out3 = {sum |pred - gt|, count(|pred - gt| > threshold), count(valid)} as doubles (the caller
+ * divides: epe = out3[0] / out3[2], rate = out3[1] / out3[2]).  gt, pred: f32[n]; out3: device double[3]. */
+int msnet_epe_badx(const float* gt, const float* pred, size_t n, float max_disp, float threshold, double* out3,
+                   msnet_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,7 @@ SIGNATURES = {
     "msnet_deconv5_softargmin": (c_int, [P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_deconv3d_cout1": (c_int, [P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_trilinear_softargmin": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "msnet_epe_badx": (c_int, [P, P, c_size_t, c_float, c_float, P, P]),
 }
 
 

@@ -20,6 +20,7 @@ SOURCES = [
     ("conv3d.hip", []),
     ("conv3d_f16s.hip", []),
     ("tail.hip", []),
+    ("metrics.hip", []),
     ("volume.hip", ["-ffp-contract=off"]),
     # -fno-slp-vectorize: hipcc otherwise packs the ZSAD add chains into v_pk_add_f32 + v_and (no |x| modifier) + v_mov
     ("volume_fused.hip", ["-ffp-contract=off", "-fno-slp-vectorize"]),

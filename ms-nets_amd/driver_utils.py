@@ -1,10 +1,11 @@
 """Host-side pieces of the reference's test driver that sit right after the forward pass:
 the crop of the padding added by generate_test_cbmv, the PFM writer / reader, the EPE / bad-x metric and the checkpoint
-key fix-up.  Plain NumPy -- nothing here touches the GPU; file decoding (cv2.imread) and dataset lists stay with the caller.
+key fix-up.  Host NumPy as in the reference, plus the metric on the device (msnet_epe_badx) when it is handed GPU tensors;
+file decoding (cv2.imread) and dataset lists stay with the caller.
 
   crop_disparity      main_msnet.py:585-589
   save_pfm / read_pfm src/utils/pfmutil.py:86-110 / :48-83   (same bytes: header 'Pf', 'W H', signed scale, rows bottom-up)
-  get_epe_rate        main_msnet.py:708-713
+  get_epe_rate        main_msnet.py:708-713      (NumPy inputs: host; GPU tensors: csrc/metrics.hip)
   strip_module_prefix keys saved from nn.DataParallel carry 'module.' (main_msnet.py:174, 509-526)
 """
 import re
@@ -63,10 +64,30 @@ def read_pfm(fname):
 
 
 def get_epe_rate(disp, prediction, max_disp=192, threshold=3.0):
-    """End-point error and bad-`threshold` rate over the pixels with 0.001 <= gt <= max_disp (main_msnet.py:708-713)."""
+    """End-point error and bad-`threshold` rate over the pixels with 0.001 <= gt <= max_disp (main_msnet.py:708-713).
+    NumPy arrays are evaluated on the host as in the reference; two GPU tensors are reduced on the device
+    (msnet_epe_badx: one HBM pass, 24 bytes back) so the disparity map never has to be copied to the host for the metric."""
+    if hasattr(disp, "is_cuda") or hasattr(prediction, "is_cuda"):
+        return get_epe_rate_gpu(disp, prediction, max_disp, threshold)
     mask = np.logical_and(disp >= 0.001, disp <= max_disp)
     err = np.abs(prediction[mask] - disp[mask])
     return np.mean(err), np.sum(err > threshold) / np.sum(mask)
+
+
+def get_epe_rate_gpu(disp, prediction, max_disp=192, threshold=3.0):
+    import torch
+    from . import _lib
+    gt = _lib.require_gpu_f32(disp, "disp")
+    pred = _lib.require_gpu_f32(prediction, "prediction")
+    if gt.shape != pred.shape:
+        raise ValueError("ground truth %s and prediction %s differ in shape" % (tuple(gt.shape), tuple(pred.shape)))
+    out = torch.empty(3, dtype=torch.float64, device=gt.device)
+    _lib.check(_lib.load().msnet_epe_badx(_lib.ptr(gt), _lib.ptr(pred), gt.numel(), float(max_disp), float(threshold), _lib.ptr(out),
+                                          _lib.stream_ptr()), "msnet_epe_badx")
+    s, bad, valid = (float(v) for v in out.cpu())
+    if valid == 0:
+        return float("nan"), float("nan")              # np.mean of an empty selection, as the reference would produce
+    return s / valid, bad / valid
 
 
 def strip_module_prefix(state_dict):

@@ -67,3 +67,21 @@ def test_images_to_volume(gpu):
     assert got.shape == ref.shape == (8, 16, (120 + pad_h) // 2, (200 + pad_w) // 2)
     assert np.array_equal(got[:4].view(np.uint32), ref[:4].view(np.uint32))
     assert np.abs(got[4:] - ref[4:]).max() <= 2e-6
+
+
+def test_epe_badx_on_device(gpu):
+    """get_epe_rate (main_msnet.py:708-713) on the device == the host formula on the same maps, including the
+    validity mask (0.001 <= gt <= max_disp) and the driver's crop of the padded rows / columns (main_msnet.py:585-589)."""
+    import torch
+    from msnets_amd import driver_utils as du
+    rng = np.random.default_rng(5)
+    gt = (rng.random((540, 960), dtype=np.float32) * 230).astype(np.float32)       # some beyond max_disp
+    gt[rng.random(gt.shape) < 0.1] = 0.0                                            # invalid pixels
+    pred_pad = (rng.random((1, 544, 960), dtype=np.float32) * 192).astype(np.float32)
+    pred = du.crop_disparity(pred_pad, 544, 960, 540, 960)
+    ref_epe, ref_rate = du.get_epe_rate(gt, pred, 192, 3.0)
+    pg = torch.from_numpy(pred_pad).cuda()[0, 4:, :960].contiguous()               # the same crop, on the device
+    epe, rate = du.get_epe_rate(torch.from_numpy(gt).cuda(), pg, 192, 3.0)
+    assert abs(epe - float(ref_epe)) <= 1e-5 * float(ref_epe) and abs(rate - float(ref_rate)) < 1e-12
+    e0, r0 = du.get_epe_rate(torch.zeros(8, 8).cuda(), torch.ones(8, 8).cuda())
+    assert np.isnan(e0) and np.isnan(r0)
