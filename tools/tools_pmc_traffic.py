@@ -50,13 +50,17 @@ if dom:
         "algorithmic_bytes": 2.0 * 96 * 272 * 480 * 32 * 4,
         "note": "conv3dbn_2 per launch; FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE exact",
     }
-vol = pick(lambda k: any(s in k for s in ("vprep_kernel", "features4_kernel", "features_kernel", "features_zsad_kernel", "sadsob_bandsum_kernel", "sadsob_band_kernel")))
+vol = pick(lambda k: any(s in k for s in ("vprep_kernel", "features4_kernel", "sadsob_bandsum_kernel", "sadsob_band_kernel")))
 if vol:
-    fb = sum(r[2] for r in vol); wb = sum(r[3] for r in vol)
+    # per MAP: a kernel may be launched more than once per build (features4_kernel: matchers 0-2, then Sobel-SAD), so every
+    # kernel's bytes are summed over all its calls and divided by the number of builds (= calls of vprep_kernel)
+    maps = max(r[1] for r in vol if "vprep_kernel" in r[0])
+    per_map = {r[0]: (r[2] * r[1] / maps, r[3] * r[1] / maps, r[1] / maps) for r in vol}
+    fb = sum(v[0] for v in per_map.values()); wb = sum(v[1] for v in per_map.values())
     src = ["volume_fused.hip", "volume.hip"]
     out["volume_build"] = {
         "workload": "cfg2", "batch_per_gpu": 1, "sources": src, "source_sha16": sha(src),
-        "kernels": {r[0]: {"fetch_bytes_x2": r[2], "write_bytes": r[3]} for r in vol},
+        "kernels": {k: {"launches_per_map": v[2], "fetch_bytes_x2": v[0], "write_bytes": v[1]} for k, v in per_map.items()},
         "hbm_bytes": fb + wb, "fetch_bytes_x2": fb, "write_bytes": wb, "algorithmic_bytes": 4.0 * 8 * 96 * 272 * 480 + 2.0 * 292 * 500,
         "note": "sum over the volume-build kernels per map; their reads are 4-byte-per-lane loads, for which the FETCH_SIZE x2 "
                 "correction is uncalibrated (MI355X_MICROARCH.md): fetch_bytes_x2 is an upper bound, write_bytes is exact",
