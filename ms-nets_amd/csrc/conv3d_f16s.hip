@@ -56,9 +56,9 @@ __device__ __forceinline__ f32x16 mfma16(half8 a, half8 b, f32x16 c) {
 
 #ifdef EXP_STAMP
 // Diagnostic build only: cycle stamps of block 0 (wave 0 = MFMA, wave 4 = loader) at every barrier of the first items.
-__device__ unsigned long long g_stamps[8][128];      // [wave][stamp]
+__device__ unsigned long long g_stamps[12][128];     // [wave][stamp]
 __device__ __forceinline__ void stamp(int role, int& idx, int lane) {
-    if (blockIdx.x == 0 && lane == 0 && idx < 128) g_stamps[role][idx] = __builtin_amdgcn_s_memtime();
+    if (blockIdx.x == 0 && lane == 0 && idx < 128 && role < 12) g_stamps[role][idx] = __builtin_amdgcn_s_memtime();
     ++idx;
 }
 #define STAMP(role, idx, lane) stamp(role, idx, lane)
@@ -240,7 +240,13 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         // three weight-group register sets as plain first-class vectors (a ring of HIP `uint4` class objects was kept in
         // scratch by hipcc, putting a memory round trip and a vmcnt wait between the L2 load and the LDS copy)
         struct BSet { u32x4 v0, v1, v2, v3, v4, v5; };
-        BSet bw0, bw1, bw2;
+        // Weight-group register sets.  Three sets = three groups of look-ahead; the six-piece groups of the Co = 64 kernels
+        // (24 registers a set) use two -- two groups, ~4.6 K cycles, is still several L2 latencies -- which is what keeps their
+        // loader inside the 256 registers of a 512-thread workgroup.  With two sets the set of group k is k & 1 and a tile has
+        // nine groups, so the item body exists once per item parity (PAR below).
+        constexpr int NSETS = NLB > 3 ? 2 : 3;
+        BSet bw[3];
+#define MSNET_SETI(J, PAR) (NSETS == 3 ? (J) % 3 : (((J) + (PAR)) & 1))
         // The tile is staged one input depth-plane at a time (PL float4 per loader thread per plane) so that the
         // copy of the NEXT tile into LDS can start before the current tile is finished: group order is kd-major, so
         // plane 0 is dead after groups 0-2 and plane 1 after groups 3-5; only planes 2.. wait for the b1/b2 window.
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         static_assert(TD == 2 && (ID == 4 || ID == 5), "plane schedule below assumes TD == 2 (input planes d*S + kd)");
         f32x4 av[ID][PL];
         unsigned goff_[PL];                             // global byte offset of the slot from the plane tile origin
-        int ihw_[PL];                                   // (ih << 8) | iw, or -1 for a slot past the plane's end
+        unsigned mask0 = 0;                             // bit u: slot u exists (not past the plane's end, not a padding channel quad)
 #pragma unroll
         for (int u = 0; u < PL; ++u) {
             const int slot = u * LT + lt;
@@ -263,14 +269,14 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             const int ih = pos / IW, iw = pos % IW;
             const bool ok = slot < PSLOT && c4 * 4 < a.Ci;      // channels beyond Ci are zero padding
             goff_[u] = (unsigned)(((ih * a.W + iw) * a.Ci + c4 * 4) * 4);
-            ihw_[u] = ok ? ((ih << 8) | iw) : -1;
+            mask0 |= (ok ? 1u : 0u) << u;
         }
         // LDS offset of this thread's slot u in plane pl: voxel = pl*IH*IW + u*(LT/VR) + lt/VR, channel quad c4 = lt % VR.
         // Swizzled records: the 16-byte slot is XORed with (iw >> 1) & 7, iw = the voxel's COLUMN in the tile.  (Keying on the
         // linear voxel index instead made the two 16-voxel rows of a 2x16 M-block -- 18 voxels apart -- collide on two of the
         // 16 slots in every ds_read_b128 lane group: 31 % of the LDS cycles of the 2x8x16 kernel were conflict cycles.)
         static_assert(!SWZ || (IW % 2 == 0), "an even row pitch keeps record parity = column parity");
-        int lhi_[ID];                                   // offset of the hi half for u = 0 (padded records)
+        const int lhi0 = (lt / VR) * RB + ((lt % VR) & 1) * 8 + (((lt % VR) >> 1) << 4);   // hi half of slot u = 0 in plane slot 0 (padded records)
         // Stride 2: a lane's voxels are two columns apart, and with 16-byte-aligned records any padded layout then puts 16
         // lanes on 8 distinct bank slots (2-way conflict on every A read: 27 % of the kernel's LDS cycles).  The columns of a
         // tile row are therefore stored de-interleaved -- even columns first, then the odd ones -- so that a tap reads
@@ -278,11 +284,6 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         constexpr bool CPERM = STRIDE == 2 && !SWZ;
         constexpr int CHALF = (IW + 1) / 2;
         int lsw_[(SWZ || CPERM) ? PL : 1];              // in-plane LDS offset of slot u (swizzle / column permutation included)
-#pragma unroll
-        for (int pl = 0; pl < ID; ++pl) {
-            const int p0 = lt / VR, c4 = lt % VR;
-            lhi_[pl] = (pl * IH * IW + p0) * RB + (c4 & 1) * 8 + ((c4 >> 1) << 4);
-        }
         if constexpr (SWZ || CPERM) {
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
@@ -304,8 +305,15 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         };
         TileCtr cur = ctr0, nxt = ctr0;                 // the current item and the one after it
         nxt.next();
-        // request slots [u0, u1) of plane pl of the tile at c
-        auto issue_a = [&](const Coord& c, int pl, int u0, int u1) {
+        // Request slots [u0, u1) of input plane pl of the tile at c into the register set `dst`.  NO load sits inside a
+        // branch: with loads on both sides of an if / else (edge vs interior tile, continuation vs column start, `if (more)`)
+        // hipcc unified the destination registers at the join with v_mov copies of loads still in flight -- i.e. an
+        // s_waitcnt vmcnt(0) in the loader's groups 0-2 that drained the next tile's HBM requests while the MFMA waves stood at
+        // the group barrier (1100-2400 cycles per barrier in the per-wave stamps).  The validity of a slot is a bit of `mask`
+        // (a plain register: the edge-tile branch only computes it), `live` = false turns the whole request into
+        // out-of-range offsets (no memory traffic, zeros returned), and the plane index may be a run-time value.
+        static_assert(PL <= 32, "slot validity mask");
+        auto issue_a = [&](f32x4 (&dst)[PL], const Coord& c, int pl, bool live, int u0, int u1) {
             const int gd = c.od0 * STRIDE - 1 + pl;
             const int ih0 = c.oh0 * STRIDE - 1, iw0 = c.ow0 * STRIDE - 1;      // input origin of the tile
             const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -315,24 +323,31 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             const unsigned base =
                 (unsigned)((((long)gd * a.H + ih0) * a.W + iw0) * a.Ci + c.chunk * CC) * 4u;
             static_assert(PL * LT >= PSLOT, "slots cover the plane");
-            const bool plane_ok = (unsigned)gd < (unsigned)a.D;
+            const bool plane_ok = live && (unsigned)gd < (unsigned)a.D;
             const bool interior = ih0 >= 0 && ih0 + IH <= a.H && iw0 >= 0 && iw0 + IW <= a.W;
+            unsigned mask = mask0;
+            if (!interior) {                            // uniform branch, VALU only
+                mask = 0;
+#pragma unroll
+                for (int u = 0; u < PL; ++u) {              // (slot position recomputed here: edge tiles only, no registers held)
+                    const int pos = (u * LT + lt) / VR;
+                    const int gh = ih0 + pos / IW, gw = iw0 + pos % IW;
+                    const bool ok = (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
+                    mask |= (ok ? 1u : 0u) << u;
+                }
+                mask &= mask0;
+            }
+            mask = plane_ok ? mask : 0u;
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
                 if (u < u0 || u >= u1) continue;
-                bool ok = ihw_[u] >= 0;
-                if (!interior) {
-                    const int gh = ih0 + (ihw_[u] >> 8), gw = iw0 + (ihw_[u] & 255);
-                    ok = ok && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
-                }
-                const unsigned voff = (ok && plane_ok) ? base + goff_[u] : 0xffffffffu;
+                const unsigned voff = ((mask >> u) & 1u) ? base + goff_[u] : 0xffffffffu;
                 const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
-                av[pl][u] = __builtin_bit_cast(f32x4, raw);
+                dst[u] = __builtin_bit_cast(f32x4, raw);
             }
         };
-        // split + copy slots [u0, u1) of plane pl into LDS (SLIDE: into plane slot (pl + 2*wrot) & 3)
-        int wrot = 0;
-        auto write_a = [&](int pl, int u0, int u1) {
+        // split + copy slots [u0, u1) of the register set `src` into LDS plane slot `pslot` (a run-time value in the sliding kernel)
+        auto write_a = [&](const f32x4 (&src)[PL], int pslot, int u0, int u1) {
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
                 if (u < u0 || u >= u1) continue;
@@ -341,14 +356,13 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #ifdef EXP_NO_SPLIT
                     {   // diagnostic: pure copy (wrong numerics) -- what the loader costs without the split VALU work
                         struct H2 { half4 a, b; };
-                        const H2 t = __builtin_bit_cast(H2, av[pl][u]);
+                        const H2 t = __builtin_bit_cast(H2, src[u]);
                         hi = t.a; lo = t.b;
                     }
 #else
-                    split4(av[pl][u], hi, lo);
+                    split4(src[u], hi, lo);
 #endif
-                    const int off = (SWZ || CPERM) ? pl * (IH * IW * RB) + lsw_[u]
-                                        : (SLIDE ? lhi_[0] + ((pl + 2 * wrot) & 3) * (IH * IW * RB) : lhi_[pl]) + u * (LT / VR) * RB;
+                    const int off = pslot * (IH * IW * RB) + ((SWZ || CPERM) ? lsw_[u] : lhi0 + u * (LT / VR) * RB);
                     *reinterpret_cast<half4*>(lds + off) = hi;
                     *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ 64) : off + HB)) = lo;
                 }
@@ -387,16 +401,16 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     } while (0)
 #endif
 #ifndef EXP_NO_GROUP_BARRIER
-#define MSNET_GROUP(G, SET)                     \
-    MSNET_WRITE_B(k0 + (G) + 1, SET);           \
-    MSNET_ISSUE_B(k0 + (G) + 1 + 3, SET);       \
-    STAMP(wave, sidx, lane);                    \
-    MSNET_LDS_BARRIER();                        \
+#define MSNET_GROUP(G, PAR)                                                 \
+    MSNET_WRITE_B(k0 + (G) + 1, bw[MSNET_SETI((G) + 1, PAR)]);              \
+    MSNET_ISSUE_B(k0 + (G) + 1 + NSETS, bw[MSNET_SETI((G) + 1, PAR)]);      \
+    STAMP(wave, sidx, lane);                                                \
+    MSNET_LDS_BARRIER();                                                    \
     STAMP(wave, sidx, lane);
 #else
-#define MSNET_GROUP(G, SET)                     \
-    MSNET_WRITE_B(k0 + (G) + 1, SET);           \
-    MSNET_ISSUE_B(k0 + (G) + 1 + 3, SET);
+#define MSNET_GROUP(G, PAR)                                                 \
+    MSNET_WRITE_B(k0 + (G) + 1, bw[MSNET_SETI((G) + 1, PAR)]);              \
+    MSNET_ISSUE_B(k0 + (G) + 1 + NSETS, bw[MSNET_SETI((G) + 1, PAR)]);
 #endif
 
         if constexpr (RESB) {
@@ -412,18 +426,16 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             {
                 const Coord c0 = coord_of(cur);
 #pragma unroll
-                for (int pl = 0; pl < ID; ++pl) issue_a(c0, pl, 0, PL);
+                for (int pl = 0; pl < ID; ++pl) issue_a(av[pl], c0, pl, true, 0, PL);
             }
             for (int it = 0; it < nitems; ++it) {
                 MSNET_LDS_BARRIER();                    // b1
 #pragma unroll
-                for (int pl = 0; pl < ID; ++pl) write_a(pl, 0, PL);
+                for (int pl = 0; pl < ID; ++pl) write_a(av[pl], pl, 0, PL);
                 MSNET_LDS_BARRIER();                    // b2
-                if (it + 1 < nitems) {
-                    const Coord c = coord_of(nxt);
+                const Coord c = coord_of(nxt);
 #pragma unroll
-                    for (int pl = 0; pl < ID; ++pl) issue_a(c, pl, 0, PL);
-                }
+                for (int pl = 0; pl < ID; ++pl) issue_a(av[pl], c, pl, it + 1 < nitems, 0, PL);
                 nxt.next();
             }
             return;
@@ -431,15 +443,20 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         {
             const Coord c0 = coord_of(cur);
 #pragma unroll
-            for (int pl = 0; pl < ID; ++pl) issue_a(c0, pl, 0, PL);
+            for (int pl = 0; pl < ID; ++pl) issue_a(av[pl], c0, pl, true, 0, PL);
         }
         {
             const int k0 = 0;
-            MSNET_ISSUE_B(0, bw0);
-            MSNET_ISSUE_B(1, bw1);
-            MSNET_ISSUE_B(2, bw2);
+            MSNET_ISSUE_B(0, bw[0]);
+            MSNET_ISSUE_B(1, bw[1]);
+            if constexpr (NSETS == 3) MSNET_ISSUE_B(2, bw[2]);
         }
         if constexpr (SLIDE) {
+            static_assert(!SLIDE || NSETS == 3, "the sliding kernel's groups are three pieces per thread");
+            // Register sets by ROLE, not by plane: av[0], av[1] hold the next item's first two missing planes (its logical planes
+            // 2, 3 inside a column, 0, 1 at a column start) -- either way they go into the LDS slots of the current item's
+            // logical planes 0 and 1 (slots 2*rot, 2*rot + 1), which die after groups 2 / 5; av[2], av[3] hold planes 2, 3 of a
+            // column start and are copied in that item's own b1/b2 window.
             constexpr int H0 = (PL + 2) / 3, H1 = (2 * PL + 2) / 3, HH = (PL + 1) / 2;
             bool early = false;                         // planes 0,1 of this column-start item were copied during the previous item
             int rot = 0;                                // plane-slot rotation of the current item
@@ -450,50 +467,36 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 const bool cs = cur.pos == 0;           // the current item starts a column: its planes 2,3 (0,1) are not resident
                 if (!cs) rot ^= 1;
                 const bool ncont = more && nxt.pos != 0;
-                // Next item: a continuation needs only its logical planes 2,3 (into the slots of this item's planes 0,1, dead
-                // after groups 2 / 5); a column start needs all four (0,1 into those slots, 2,3 in its own b1/b2 window).
                 const Coord nx = coord_of(nxt);
-#ifdef EXP_HOIST
-                // Experiment (measured, not shipped): inside a column, request the next tile's two new planes HERE, before b1,
-                // instead of during groups 0 / 1.  The per-wave stamps (tools_stamps.py) show the loader's groups 0 and 1 taking
-                // ~2600 cycles against ~1450 for the MFMA waves, which wait ~1100 cycles at each of those two barriers; hoisted,
-                // those waits disappear but the same ~1000 cycles reappear as a wait at b1 and the MFMA waves' own hand-over code
-                // slows down (the two waves of a SIMD share its issue port): 2.32 vs 2.29 ms on conv3dbn_2.
-                const bool hoist = ncont && !cs;
-#else
-                const bool hoist = false;
-#endif
-                if (hoist) { issue_a(nx, 2, 0, PL); issue_a(nx, 3, 0, PL); }
+                const int p0 = ncont ? 2 : 0;           // first missing plane of the next item
                 STAMP(wave, sidx, lane);
                 MSNET_LDS_BARRIER();                    // b1: MFMA waves are done with the previous tile
                 STAMP(wave, sidx, lane);
-                wrot = rot;
-                if (cs) {
-                    if (!early) { write_a(0, 0, PL); write_a(1, 0, PL); }
-                    write_a(2, 0, PL); write_a(3, 0, PL);
+                if (cs) {                               // (LDS copies only inside the branches)
+                    if (!early) { write_a(av[0], (2 * rot) & 3, 0, PL); write_a(av[1], (2 * rot + 1) & 3, 0, PL); }
+                    write_a(av[2], (2 * rot + 2) & 3, 0, PL); write_a(av[3], (2 * rot + 3) & 3, 0, PL);
                 }
-                MSNET_WRITE_B(k0, bw0);
-                MSNET_ISSUE_B(k0 + 3, bw0);
+                MSNET_WRITE_B(k0, bw[0]);
+                MSNET_ISSUE_B(k0 + 3, bw[0]);
                 STAMP(wave, sidx, lane);
                 MSNET_LDS_BARRIER();                    // b2: tile and group 0 are in LDS
                 STAMP(wave, sidx, lane);
-                wrot = ncont ? rot ^ 1 : rot;
-                if (more && !hoist) { if (ncont) issue_a(nx, 2, 0, PL); else { issue_a(nx, 0, 0, PL); issue_a(nx, 1, 0, HH); } }
-                MSNET_GROUP(0, bw1)
-                if (more && !hoist) { if (ncont) issue_a(nx, 3, 0, PL); else { issue_a(nx, 1, HH, PL); issue_a(nx, 2, 0, PL); } }
-                MSNET_GROUP(1, bw2)
-                if (more && !ncont) issue_a(nx, 3, 0, PL);
-                MSNET_GROUP(2, bw0)                     // g_2 passed: this item's logical plane 0 is dead
-                if (more) { if (ncont) write_a(2, 0, H0); else write_a(0, 0, H0); }
-                MSNET_GROUP(3, bw1)
-                if (more) { if (ncont) write_a(2, H0, H1); else write_a(0, H0, H1); }
-                MSNET_GROUP(4, bw2)
-                if (more) { if (ncont) write_a(2, H1, PL); else write_a(0, H1, PL); }
-                MSNET_GROUP(5, bw0)                     // g_5 passed: logical plane 1 is dead
-                if (more) { if (ncont) write_a(3, 0, HH); else write_a(1, 0, HH); }
-                MSNET_GROUP(6, bw1)
-                if (more) { if (ncont) write_a(3, HH, PL); else write_a(1, HH, PL); }
-                MSNET_GROUP(7, bw2)
+                issue_a(av[0], nx, p0, more, 0, PL); issue_a(av[1], nx, p0 + 1, more, 0, HH);
+                MSNET_GROUP(0, 0)
+                issue_a(av[1], nx, p0 + 1, more, HH, PL); issue_a(av[2], nx, 2, more && !ncont, 0, PL);
+                MSNET_GROUP(1, 0)
+                issue_a(av[3], nx, 3, more && !ncont, 0, PL);
+                MSNET_GROUP(2, 0)                     // g_2 passed: this item's logical plane 0 (slot 2*rot) is dead
+                write_a(av[0], 2 * rot, 0, H0);
+                MSNET_GROUP(3, 0)
+                write_a(av[0], 2 * rot, H0, H1);
+                MSNET_GROUP(4, 0)
+                write_a(av[0], 2 * rot, H1, PL);
+                MSNET_GROUP(5, 0)                     // g_5 passed: logical plane 1 (slot 2*rot + 1) is dead
+                write_a(av[1], 2 * rot + 1, 0, HH);
+                MSNET_GROUP(6, 0)
+                write_a(av[1], 2 * rot + 1, HH, PL);
+                MSNET_GROUP(7, 0)
                 early = more && !ncont;
                 cur = nxt; nxt.next();
             }
@@ -504,64 +507,83 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         // The loader shares each SIMD with an MFMA wave and runs ~3x slower than alone, so its per-item work (28 loads,
         // 28 split+copy, 27 weight pieces) is spread evenly over the nine group slots instead of bunched at the barriers.
         constexpr int H0 = (PL + 2) / 3, H1 = (2 * PL + 2) / 3, HH = (PL + 1) / 2;
-        for (int it = 0; it < nitems; ++it) {
-            const int k0 = it * 9;                      // 9 % 3 == 0: group k0+g always uses set g % 3
+        auto item = [&](auto parc, const int it) {
+            [[maybe_unused]] constexpr int PAR = decltype(parc)::value;  // it & 1 (two sets); unused with three (9 % 3 == 0: group k0+g uses set g % 3)
+            const int k0 = it * 9;
             const bool more = it + 1 < nitems;
             STAMP(wave, sidx, lane);
             MSNET_LDS_BARRIER();                        // b1: MFMA waves are done with the previous tile
             STAMP(wave, sidx, lane);
 #ifndef EXP_NO_A_STAGE
-            if (!early) { write_a(0, 0, PL); write_a(1, 0, PL); }
-            write_a(2, 0, PL); write_a(3, 0, PL);
-            if constexpr (ID > 4) write_a(4, 0, PL);
+            if (!early) { write_a(av[0], 0, 0, PL); write_a(av[1], 1, 0, PL); }
+            write_a(av[2], 2, 0, PL); write_a(av[3], 3, 0, PL);
+            if constexpr (ID > 4) write_a(av[4], 4, 0, PL);
 #endif
-            MSNET_WRITE_B(k0, bw0);
-            MSNET_ISSUE_B(k0 + 3, bw0);
+            MSNET_WRITE_B(k0, bw[MSNET_SETI(0, PAR)]);
+            MSNET_ISSUE_B(k0 + NSETS, bw[MSNET_SETI(0, PAR)]);
             STAMP(wave, sidx, lane);
             MSNET_LDS_BARRIER();                        // b2: tile and group 0 are in LDS
             STAMP(wave, sidx, lane);
             // group g+1 is copied to LDS (and group g+4 requested) while group g is multiplied; barrier g_g ends it.
-            // The next tile is requested during groups 0-2; its planes 0 / 1 are copied as soon as they are dead.
+            // The next tile is requested during groups 0-2; its planes 0 / 1 are copied as soon as they are dead.  (Past the
+            // last item the requests are dead -- `more` = false -- and the copies put zeros into planes nobody reads again.)
             const Coord nx = coord_of(nxt);
+            // Stride 2 (five planes, 104 KB per item and CU next to a weight stream of the same size): one plane per group over
+            // groups 0-4 instead of everything in groups 0-2 -- the per-wave stamps showed single buffer loads taking 300-500
+            // cycles to ISSUE in that burst (the CU's outstanding-request capacity), which the MFMA waves then sat out at g_0-g_2.
+            constexpr bool SPREAD = ID > 4;
 #ifndef EXP_NO_A_STAGE
-            if (more) { issue_a(nx, 0, 0, PL); issue_a(nx, 1, 0, HH); }
+            if constexpr (SPREAD) issue_a(av[0], nx, 0, more, 0, PL);
+            else { issue_a(av[0], nx, 0, more, 0, PL); issue_a(av[1], nx, 1, more, 0, HH); }
 #endif
-            MSNET_GROUP(0, bw1)
+            MSNET_GROUP(0, PAR)
 #ifndef EXP_NO_A_STAGE
-            if (more) { issue_a(nx, 1, HH, PL); issue_a(nx, 2, 0, PL); }
+            if constexpr (SPREAD) issue_a(av[1], nx, 1, more, 0, PL);
+            else { issue_a(av[1], nx, 1, more, HH, PL); issue_a(av[2], nx, 2, more, 0, PL); }
 #endif
-            MSNET_GROUP(1, bw2)
+            MSNET_GROUP(1, PAR)
 #ifndef EXP_NO_A_STAGE
-            if (more) issue_a(nx, 3, 0, PL);
-            if constexpr (ID > 4) { if (more) issue_a(nx, 4, 0, PL); }
+            if constexpr (SPREAD) issue_a(av[2], nx, 2, more, 0, PL);
+            else issue_a(av[3], nx, 3, more, 0, PL);
 #endif
-            MSNET_GROUP(2, bw0)                         // g_2 passed: kd = 0 groups done, plane 0 is dead
+            MSNET_GROUP(2, PAR)                         // g_2 passed: kd = 0 groups done, plane 0 is dead
 #ifndef EXP_NO_A_STAGE
-            if (more) write_a(0, 0, H0);
+            if constexpr (SPREAD) issue_a(av[3], nx, 3, more, 0, PL);
+            write_a(av[0], 0, 0, H0);
 #endif
-            MSNET_GROUP(3, bw1)
+            MSNET_GROUP(3, PAR)
 #ifndef EXP_NO_A_STAGE
-            if (more) write_a(0, H0, H1);
+            if constexpr (SPREAD) issue_a(av[4], nx, 4, more, 0, PL);
+            write_a(av[0], 0, H0, H1);
 #endif
-            MSNET_GROUP(4, bw2)
+            MSNET_GROUP(4, PAR)
 #ifndef EXP_NO_A_STAGE
-            if (more) write_a(0, H1, PL);
+            write_a(av[0], 0, H1, PL);
 #endif
-            MSNET_GROUP(5, bw0)                         // g_5 passed: kd = 1 groups done, plane 1 is dead
+            MSNET_GROUP(5, PAR)                         // g_5 passed: kd = 1 groups done, plane 1 is dead
 #ifndef EXP_NO_A_STAGE
-            if (more) write_a(1, 0, HH);
+            write_a(av[1], 1, 0, HH);
 #endif
-            MSNET_GROUP(6, bw1)
+            MSNET_GROUP(6, PAR)
 #ifndef EXP_NO_A_STAGE
-            if (more) write_a(1, HH, PL);
+            write_a(av[1], 1, HH, PL);
 #endif
-            MSNET_GROUP(7, bw2)
+            MSNET_GROUP(7, PAR)
             early = more;
             cur = nxt; nxt.next();
+        };
+        if constexpr (NSETS == 3) {
+            for (int it = 0; it < nitems; ++it) item(std::integral_constant<int, 0>{}, it);
+        } else {
+            for (int it = 0; it < nitems; it += 2) {
+                item(std::integral_constant<int, 0>{}, it);
+                if (it + 1 < nitems) item(std::integral_constant<int, 1>{}, it + 1);
+            }
         }
 #undef MSNET_GROUP
 #undef MSNET_WRITE_B
 #undef MSNET_ISSUE_B
+#undef MSNET_SETI
         return;
     }
 
@@ -1687,7 +1709,7 @@ using namespace msnet;
 
 #ifdef EXP_STAMP
 extern "C" int msnet_debug_read_stamps(unsigned long long* host) {
-    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 1024) == hipSuccess ? 0 : 1;
+    return hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 12 * 128) == hipSuccess ? 0 : 1;
 }
 #endif
 

@@ -12,6 +12,7 @@ LAYERS = {
     "c8":        ("conv", 8, 32, 1, (96, 272, 480), False),
     "s1_32_32":  ("conv", 32, 32, 1, (96, 272, 480), False),
     "s2_32_64":  ("conv", 32, 64, 2, (96, 272, 480), False),
+    "s2_16_64":  ("conv", 16, 64, 2, (96, 272, 480), False),     # (not a network layer: stride-2 staging with full-line requests)
     "s1_64_64":  ("conv", 64, 64, 1, (48, 136, 240), False),
     "s2_64_64":  ("conv", 64, 64, 2, (48, 136, 240), False),
     "s1_64_64b": ("conv", 64, 64, 1, (24, 68, 120), False),
