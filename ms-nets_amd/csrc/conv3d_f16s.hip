@@ -620,26 +620,65 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     int pn = 0, pod0 = 0, poh0 = 0, pow0 = 0, pcg = 0;  // coordinates of the item whose epilogue is pending
     bool pending = false;
 
+    // Epilogue of a finished tile over buffer descriptors (an element outside the tensor gets offset 0xffffffff: load 0 / store
+    // dropped, no branch).  vmcnt counts stores as well as loads on this part, so nothing here may wait for "all loads": the
+    // earlier form joined an optional residual load with the stores of every 32x32 block, and the s_waitcnt vmcnt(0) at that
+    // join made each block of 16 stores wait for the ACKNOWLEDGEMENT of the previous block's stores (the per-wave stamps showed
+    // 5.0-5.7 K cycles for the 64 KB of a Co = 64 tile).  Without a residual there is no load and no wait at all; with one, the
+    // residual of block b+1 is requested before block b is stored, so the counted wait for it leaves b's stores in flight.
+    const size_t osample = (size_t)a.OD * a.OH * a.OW * a.Co * 4;
     auto epilogue = [&](int n, int od0, int oh0, int ow0, int cg) {
-        const bool full_hw = (oh0 + TH <= a.OH) && (ow0 + TW <= a.OW);
-#pragma unroll
-        for (int i = 0; i < MB; ++i) {
+        const auto rs_y = make_rsrc(a.y + (size_t)n * (osample / 4), osample);
+        constexpr int NBLK = MB * NB;
+        auto geom = [&](int b, unsigned& off, bool& rowok, int& hlim, int& wlim, float& sc, float& sh) {
+            const int i = b / NB, j = b % NB;
             const int mb = wm * MB + i;
             const int bw_ = mb % MW, bh = (mb / MW) % MH, bd = mb / (MW * MH);
-            const int od = od0 + bd;
-            if (od >= a.OD) continue;
-            const int ohb = oh0 + bh * BH, owb = ow0 + bw_ * BW + 4 * hh;
+            const int od = od0 + bd, ohb = oh0 + bh * BH, owb = ow0 + bw_ * BW + 4 * hh;
+            const int co = (cg * NB + j) * 32 + r;
+            sc = a.scale ? a.scale[co] : 1.f;
+            sh = a.shift ? a.shift[co] : 0.f;
+            rowok = od < a.OD;
+            hlim = a.OH - ohb; wlim = a.OW - owb;
+            off = (unsigned)((((size_t)od * a.OH + ohb) * a.OW + owb) * a.Co + co) * 4u;
+        };
+        auto block_acc = [&](int b) {
+            f32x16 v;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int co = (cg * NB + j) * 32 + r;
-                const float sc = a.scale ? a.scale[co] : 1.f;
-                const float sh = a.shift ? a.shift[co] : 0.f;
-                f32x16 v;
+            for (int e = 0; e < 16; ++e) v[e] = acc0[b / NB][b % NB][e] + acc1[b / NB][b % NB][e] * kLoInv;
+            return v;
+        };
+        if (!a.res) {
+            f32x16 zero;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
-                const size_t base = ((((size_t)n * a.OD + od) * a.OH + ohb) * a.OW + owb) * a.Co + co;
-                epilogue_block<BW>(v, sc, sh, a.res, a.y, base, stride_h, stride_w, a.relu, full_hw,
-                                   [&](int lh, int lw) { return ohb + lh < a.OH && owb + lw < a.OW; }, a.oflag);
+            for (int e = 0; e < 16; ++e) zero[e] = 0.f;
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                unsigned off; bool rowok; int hlim, wlim; float sc, sh;
+                geom(b, off, rowok, hlim, wlim, sc, sh);
+                epilogue_store<BW>(block_acc(b), zero, sc, sh, rs_y, off, stride_h * 4, stride_w * 4, a.relu,
+                                   [&](int lh, int lw) { return rowok && lh < hlim && lw < wlim; }, a.oflag);
+            }
+        } else {
+            const auto rs_res = make_rsrc(a.res + (size_t)n * (osample / 4), osample);
+            f32x16 rv[2];
+            {
+                unsigned off; bool rowok; int hlim, wlim; float sc, sh;
+                geom(0, off, rowok, hlim, wlim, sc, sh);
+                residual_prefetch<BW>(rv[0], rs_res, off, stride_h * 4, stride_w * 4, [&](int lh, int lw) { return rowok && lh < hlim && lw < wlim; });
+            }
+#pragma unroll
+            for (int b = 0; b < NBLK; ++b) {
+                if (b + 1 < NBLK) {
+                    unsigned off; bool rowok; int hlim, wlim; float sc, sh;
+                    geom(b + 1, off, rowok, hlim, wlim, sc, sh);
+                    residual_prefetch<BW>(rv[(b + 1) & 1], rs_res, off, stride_h * 4, stride_w * 4,
+                                          [&](int lh, int lw) { return rowok && lh < hlim && lw < wlim; });
+                }
+                unsigned off; bool rowok; int hlim, wlim; float sc, sh;
+                geom(b, off, rowok, hlim, wlim, sc, sh);
+                epilogue_store<BW>(block_acc(b), rv[b & 1], sc, sh, rs_y, off, stride_h * 4, stride_w * 4, a.relu,
+                                   [&](int lh, int lw) { return rowok && lh < hlim && lw < wlim; }, a.oflag);
             }
         }
     };
@@ -662,7 +701,6 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     for (int j = 0; j < NB; ++j) { psc[j] = 1.f; psh[j] = 0.f; }
     __amdgpu_buffer_rsrc_t pend_rs = make_rsrc(a.y, 0);
     auto park = [&](int n, int od0, int oh0, int ow0, int cg) {
-        const size_t osample = (size_t)a.OD * a.OH * a.OW * a.Co * 4;
         pend_rs = make_rsrc(a.y + (size_t)n * (osample / 4), osample);
 #pragma unroll
         for (int i = 0; i < MB; ++i) {
@@ -1443,28 +1481,38 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(Co
         });
         // epilogue: lane = output channel, register e = voxel (e&3) + 8*(e>>2) + 4*hh of the 32-voxel row
         const auto rs_y = make_rsrc(a.y + (size_t)n * (osample / 4), osample);
-        const auto rs_res = make_rsrc(a.res ? a.res + (size_t)n * (osample / 4) : nullptr, a.res ? osample : 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        // (no load and no s_waitcnt between the stores when there is no residual -- the first layer's case; vmcnt counts stores too,
+        // so a wait at an "optional residual" join would hold every block until the previous block's stores are acknowledged)
+        auto block = [&](int b, unsigned& off, bool& rowok, int& wlim, float& sc, float& sh, f32x16& v) {
+            const int i = b / NB, j = b % NB;
             const int od = d0 + (wave >> 1), oh = h0 + (wave & 1) * 2 + i, owb = w0 + 4 * hh;
-            const bool rowok = od < a.OD && oh < a.OH;
+            const int co = j * 32 + r;
+            rowok = od < a.OD && oh < a.OH;
+            wlim = a.OW - owb;
+            sc = a.scale ? a.scale[co] : 1.f;
+            sh = a.shift ? a.shift[co] : 0.f;
+            off = (unsigned)((((size_t)od * a.OH + oh) * a.OW + owb) * a.Co + co) * 4u;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const int co = j * 32 + r;
-                const float sc = a.scale ? a.scale[co] : 1.f;
-                const float sh = a.shift ? a.shift[co] : 0.f;
-                const unsigned off = (unsigned)((((size_t)od * a.OH + oh) * a.OW + owb) * a.Co + co) * 4u;
-                auto valid = [&](int, int lw) { return rowok && owb + lw < a.OW; };
-                f32x16 v, rv;
+            for (int e = 0; e < 16; ++e) v[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
+        };
+        if (!a.res) {
+            f32x16 zero;
 #pragma unroll
-                for (int e = 0; e < 16; ++e) v[e] = acc0[i][j][e] + acc1[i][j][e] * kLoInv;
-                if (a.res) {
-                    residual_prefetch<32>(rv, rs_res, off, 0, a.Co * 4, valid);
-                } else {                                // (the first layer has no residual: no point in 16 loads that return zero)
+            for (int e = 0; e < 16; ++e) zero[e] = 0.f;
 #pragma unroll
-                    for (int e = 0; e < 16; ++e) rv[e] = 0.f;
-                }
-                epilogue_store<32>(v, rv, sc, sh, rs_y, off, 0, a.Co * 4, a.relu, valid, a.oflag);
+            for (int b = 0; b < 2 * NB; ++b) {
+                unsigned off; bool rowok; int wlim; float sc, sh; f32x16 v;
+                block(b, off, rowok, wlim, sc, sh, v);
+                epilogue_store<32>(v, zero, sc, sh, rs_y, off, 0, a.Co * 4, a.relu, [&](int, int lw) { return rowok && lw < wlim; }, a.oflag);
+            }
+        } else {
+            const auto rs_res = make_rsrc(a.res + (size_t)n * (osample / 4), osample);
+#pragma unroll
+            for (int b = 0; b < 2 * NB; ++b) {
+                unsigned off; bool rowok; int wlim; float sc, sh; f32x16 v, rv;
+                block(b, off, rowok, wlim, sc, sh, v);
+                residual_prefetch<32>(rv, rs_res, off, 0, a.Co * 4, [&](int, int lw) { return rowok && lw < wlim; });
+                epilogue_store<32>(v, rv, sc, sh, rs_y, off, 0, a.Co * 4, a.relu, [&](int, int lw) { return rowok && lw < wlim; }, a.oflag);
             }
         }
     }
@@ -1654,8 +1702,8 @@ static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     a.ngroups = a.Co / (32 * NB); a.nbtot = a.Co / 32;
     const size_t ntiles = (size_t)a.N * a.ntd * a.nth * a.ntw * a.ngroups;
     if (ntiles == 0 || ntiles > 0x7fffffffu) return fail("%s: bad tile count %zu", name, ntiles);
-    if ((size_t)a.D * a.H * a.W * a.Ci * 4 > 0x7ffffff0u)
-        return fail("%s: an input sample exceeds 2 GB, the range of the loaders' buffer descriptor (use the fp32 path)", name);
+    if ((size_t)a.D * a.H * a.W * a.Ci * 4 > 0x7ffffff0u || (size_t)a.OD * a.OH * a.OW * a.Co * 4 > 0xfffffff0u)
+        return fail("%s: a sample exceeds the range of the kernel's buffer descriptors (2 GB in, 4 GB out; use the fp32 path)", name);
     const size_t nblk = ntiles < (size_t)num_cus() ? ntiles : (size_t)num_cus();
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
