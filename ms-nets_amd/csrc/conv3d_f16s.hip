@@ -1076,22 +1076,32 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void deconv3d
         BSet bw0, bw1, bw2;
         f32x4 av[NL];
         const size_t sample_bytes = (size_t)a.D * a.H * a.W * a.Ci * 4;
-        auto issue_a = [&](int it) {
-            int n, d0, h0, w0, cg;
-            decode(it, n, d0, h0, w0, cg);
-            const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float*>(a.x) + (size_t)n * (sample_bytes / 4), 0, (int)sample_bytes, 0x00020000);
-            const unsigned base = (unsigned)((((long)d0 * a.H + h0) * a.W + w0) * a.Ci) * 4u;
+        // The next tile is requested a few loads per weight group (NL = 30 per thread: as one burst behind b2 the loader spent
+        // several groups just issuing them, and its weight copies -- which the MFMA waves wait for at every group barrier -- queued
+        // up behind).  `live` = false (past the last item) turns the requests into out-of-range offsets.
+        int nx_d0 = 0, nx_h0 = 0, nx_w0 = 0;
+        unsigned nx_base = 0;
+        bool nx_live = false;
+        __amdgpu_buffer_rsrc_t nx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, 0, 0x00020000);
+        auto prep_a = [&](int it, bool live) {
+            int n, cg;
+            decode(live ? it : 0, n, nx_d0, nx_h0, nx_w0, cg);
+            nx_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)n * (sample_bytes / 4), 0, (int)sample_bytes, 0x00020000);
+            nx_base = (unsigned)((((long)nx_d0 * a.H + nx_h0) * a.W + nx_w0) * a.Ci) * 4u;
+            nx_live = live;
+        };
+        auto issue_part = [&](int u0, int u1) {
             int ltv = lt;
             asm volatile("" : "+v"(ltv));               // keep the per-slot index math inside the loop (registers)
 #pragma unroll
             for (int u = 0; u < NL; ++u) {
+                if (u < u0 || u >= u1) continue;
                 const int slot = u * LT + ltv;
                 const int pos = slot / V, c4 = slot % V;
                 const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
-                const bool ok = slot < NSLOT && d0 + id < a.D && h0 + ih < a.H && w0 + iw < a.W;
-                const unsigned voff = ok ? base + (unsigned)((((id * a.H + ih) * a.W + iw) * a.Ci + c4 * 4) * 4) : 0xffffffffu;
-                av[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+                const bool ok = nx_live && slot < NSLOT && nx_d0 + id < a.D && nx_h0 + ih < a.H && nx_w0 + iw < a.W;
+                const unsigned voff = ok ? nx_base + (unsigned)((((id * a.H + ih) * a.W + iw) * a.Ci + c4 * 4) * 4) : 0xffffffffu;
+                av[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(nx_rsrc, voff, 0, 0));
             }
         };
         auto write_a = [&]() {
@@ -1141,12 +1151,16 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void deconv3d
 #if defined(DEXP_NO_B)
 #define MSNET_DGROUP(G, SET) MSNET_DBAR();
 #else
-#define MSNET_DGROUP(G, SET)                    \
-    MSNET_WRITE_B(k0 + (G) + 1, SET);           \
-    MSNET_ISSUE_B(k0 + (G) + 1 + 3, SET);       \
+// group G: copy group G+1's weights, request group G+4's, then this group's share of the next tile (APG loads), barrier
+#define MSNET_DGROUP(G, SET)                                                        \
+    MSNET_WRITE_B(k0 + (G) + 1, SET);                                               \
+    MSNET_ISSUE_B(k0 + (G) + 1 + 3, SET);                                           \
+    if constexpr ((G) * APG < NL) issue_part((G) * APG, (G) * APG + APG);           \
     MSNET_DBAR();
 #endif
-        issue_a(0);
+        constexpr int APG = (NL + 19) / 20;             // loads per group: the tile is complete after at most 20 of the 26 groups
+        prep_a(0, true);
+        issue_part(0, NL);
         cg_cur = cg_of(0); cg_next = cg_of(1);
         MSNET_ISSUE_B(0, bw0);
         MSNET_ISSUE_B(1, bw1);
@@ -1161,9 +1175,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void deconv3d
             MSNET_WRITE_B(k0, bw0);
             MSNET_ISSUE_B(k0 + 3, bw0);
             MSNET_LDS_BARRIER();                        // b2: tile and group 0 are in LDS
-#ifndef DEXP_NO_A
-            if (it + 1 < nitems) issue_a(it + 1);
-#endif
+            prep_a(it + 1, it + 1 < nitems);
             MSNET_DGROUP(0, bw1)  MSNET_DGROUP(1, bw2)  MSNET_DGROUP(2, bw0)  MSNET_DGROUP(3, bw1)  MSNET_DGROUP(4, bw2)
             MSNET_DGROUP(5, bw0)  MSNET_DGROUP(6, bw1)  MSNET_DGROUP(7, bw2)  MSNET_DGROUP(8, bw0)  MSNET_DGROUP(9, bw1)
             MSNET_DGROUP(10, bw2) MSNET_DGROUP(11, bw0) MSNET_DGROUP(12, bw1) MSNET_DGROUP(13, bw2) MSNET_DGROUP(14, bw0)
