@@ -204,7 +204,11 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     constexpr int NLB = (PG + LT - 1) / LT;               // pieces per loader thread per group
     static_assert(TD * MH * MW == 4 * MB, "M-block count mismatch");
     static_assert(NLB == 2 || NLB == 3 || NLB == 6, "weight group = 2, 3 or 6 16-byte pieces per loader thread");
-    constexpr int NBUF = RESB ? 9 : 2;                  // weight-group buffers in LDS
+    // Weight-group buffers in LDS.  B3 (three buffers, where they fit: the Co = 32 stride-1 kernels): group g+2 is copied while
+    // group g is multiplied, so group g+1 has been in LDS since barrier g_(g-1) and its first B fragments are read BEFORE
+    // barrier g_g, like the A fragments -- with two buffers every group started with an exposed LDS round trip behind its barrier.
+    constexpr bool B3 = !RESB && STRIDE == 1 && NB == 1 && NPOS * RB + 3 * GB <= 160 * 1024;
+    constexpr int NBUF = RESB ? 9 : (B3 ? 3 : 2);
     static_assert(NPOS * RB + NBUF * GB <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) unsigned char lds[NPOS * RB + NBUF * GB];
     unsigned char* const lds_b = lds + NPOS * RB;
@@ -245,6 +249,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         // loader inside the 256 registers of a 512-thread workgroup.  With two sets the set of group k is k & 1 and a tile has
         // nine groups, so the item body exists once per item parity (PAR below).
         constexpr int NSETS = NLB > 3 ? 2 : 3;
+        constexpr int BA = B3 ? 2 : 1;
+        static_assert(!B3 || NSETS == 3, "three LDS buffers go with three register sets");
         BSet bw[3];
 #define MSNET_SETI(J, PAR) (NSETS == 3 ? (J) % 3 : (((J) + (PAR)) & 1))
         // The tile is staged one input depth-plane at a time (PL float4 per loader thread per plane) so that the
@@ -394,24 +400,37 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     } while (0)
 #define MSNET_WRITE_B(K, SET)                                                                                      \
     do {                                                                                                           \
-        u32x4* dst_ = reinterpret_cast<u32x4*>(lds_b + ((K) & 1) * GB);                                            \
+        u32x4* dst_ = reinterpret_cast<u32x4*>(lds_b + (B3 ? ((K) - k0) % 3 : ((K) & 1)) * GB);                    \
         dst_[bi_[0]] = SET.v0; dst_[bi_[1]] = SET.v1;                                                              \
         if constexpr (NLB > 2) dst_[bi_[2]] = SET.v2;                                                              \
         if constexpr (NLB > 3) { dst_[3 * LT + lt] = SET.v3; dst_[4 * LT + lt] = SET.v4; dst_[5 * LT + lt] = SET.v5; }    \
     } while (0)
 #endif
 #ifndef EXP_NO_GROUP_BARRIER
-#define MSNET_GROUP(G, PAR)                                                 \
-    MSNET_WRITE_B(k0 + (G) + 1, bw[MSNET_SETI((G) + 1, PAR)]);              \
-    MSNET_ISSUE_B(k0 + (G) + 1 + NSETS, bw[MSNET_SETI((G) + 1, PAR)]);      \
-    STAMP(wave, sidx, lane);                                                \
-    MSNET_LDS_BARRIER();                                                    \
+// slot of group G: copy group G + BA (BA = 2 with three LDS buffers, else 1) and request the group NSETS later into the freed set
+#define MSNET_GROUP(G, PAR)                                                         \
+    MSNET_WRITE_B(k0 + (G) + BA, bw[MSNET_SETI((G) + BA, PAR)]);                    \
+    MSNET_ISSUE_B(k0 + (G) + BA + NSETS, bw[MSNET_SETI((G) + BA, PAR)]);            \
+    STAMP(wave, sidx, lane);                                                        \
+    MSNET_LDS_BARRIER();                                                            \
     STAMP(wave, sidx, lane);
 #else
-#define MSNET_GROUP(G, PAR)                                                 \
-    MSNET_WRITE_B(k0 + (G) + 1, bw[MSNET_SETI((G) + 1, PAR)]);              \
-    MSNET_ISSUE_B(k0 + (G) + 1 + NSETS, bw[MSNET_SETI((G) + 1, PAR)]);
+#define MSNET_GROUP(G, PAR)                                                         \
+    MSNET_WRITE_B(k0 + (G) + BA, bw[MSNET_SETI((G) + BA, PAR)]);                    \
+    MSNET_ISSUE_B(k0 + (G) + BA + NSETS, bw[MSNET_SETI((G) + BA, PAR)]);
 #endif
+// b1/b2 window: two buffers -- group 0 of the item; three -- nothing (groups 0, 1 were copied during the previous item)
+#define MSNET_WINDOW_B(PAR)                                                         \
+    if constexpr (!B3) {                                                            \
+        MSNET_WRITE_B(k0, bw[MSNET_SETI(0, PAR)]);                                  \
+        MSNET_ISSUE_B(k0 + NSETS, bw[MSNET_SETI(0, PAR)]);                          \
+    }
+// behind g_7 (three buffers only): the next item's group 1 goes into the buffer group 7 has just released
+#define MSNET_TAIL_B(PAR)                                                           \
+    if constexpr (B3) {                                                             \
+        MSNET_WRITE_B(k0 + 10, bw[MSNET_SETI(10, PAR)]);                            \
+        MSNET_ISSUE_B(k0 + 10 + NSETS, bw[MSNET_SETI(10, PAR)]);                    \
+    }
 
         if constexpr (RESB) {
             for (int p = lt * 16; p < NPOS * RB; p += LT * 16)      // zero the records once (padding channels stay zero)
@@ -450,6 +469,10 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             MSNET_ISSUE_B(0, bw[0]);
             MSNET_ISSUE_B(1, bw[1]);
             if constexpr (NSETS == 3) MSNET_ISSUE_B(2, bw[2]);
+            if constexpr (B3) {                         // groups 0 and 1 of the first item (nobody reads the buffers before b2)
+                MSNET_WRITE_B(0, bw[0]); MSNET_ISSUE_B(3, bw[0]);
+                MSNET_WRITE_B(1, bw[1]); MSNET_ISSUE_B(4, bw[1]);
+            }
         }
         if constexpr (SLIDE) {
             static_assert(!SLIDE || NSETS == 3, "the sliding kernel's groups are three pieces per thread");
@@ -476,8 +499,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                     if (!early) { write_a(av[0], (2 * rot) & 3, 0, PL); write_a(av[1], (2 * rot + 1) & 3, 0, PL); }
                     write_a(av[2], (2 * rot + 2) & 3, 0, PL); write_a(av[3], (2 * rot + 3) & 3, 0, PL);
                 }
-                MSNET_WRITE_B(k0, bw[0]);
-                MSNET_ISSUE_B(k0 + 3, bw[0]);
+                MSNET_WINDOW_B(0)
                 STAMP(wave, sidx, lane);
                 MSNET_LDS_BARRIER();                    // b2: tile and group 0 are in LDS
                 STAMP(wave, sidx, lane);
@@ -497,6 +519,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 MSNET_GROUP(6, 0)
                 write_a(av[1], 2 * rot + 1, HH, PL);
                 MSNET_GROUP(7, 0)
+                MSNET_TAIL_B(0)
                 early = more && !ncont;
                 cur = nxt; nxt.next();
             }
@@ -519,8 +542,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             write_a(av[2], 2, 0, PL); write_a(av[3], 3, 0, PL);
             if constexpr (ID > 4) write_a(av[4], 4, 0, PL);
 #endif
-            MSNET_WRITE_B(k0, bw[MSNET_SETI(0, PAR)]);
-            MSNET_ISSUE_B(k0 + NSETS, bw[MSNET_SETI(0, PAR)]);
+            MSNET_WINDOW_B(PAR)
             STAMP(wave, sidx, lane);
             MSNET_LDS_BARRIER();                        // b2: tile and group 0 are in LDS
             STAMP(wave, sidx, lane);
@@ -569,6 +591,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             write_a(av[1], 1, HH, PL);
 #endif
             MSNET_GROUP(7, PAR)
+            MSNET_TAIL_B(PAR)
             early = more;
             cur = nxt; nxt.next();
         };
@@ -581,6 +604,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             }
         }
 #undef MSNET_GROUP
+#undef MSNET_WINDOW_B
+#undef MSNET_TAIL_B
 #undef MSNET_WRITE_B
 #undef MSNET_ISSUE_B
 #undef MSNET_SETI
@@ -853,7 +878,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         const u32x4* const wnxt = wbase_of(it + 1);
 #endif
         auto do_group = [&](int g, auto drain) {
-            const unsigned char* bb = lds_b + (RESB ? g : ((gg0 + g) & 1)) * GB + lane * 16;
+            const int g3 = g - 3 * ((g * 11) >> 5);     // g % 3 (g < 9)
+            const unsigned char* bb = lds_b + (RESB ? g : (B3 ? g3 : ((gg0 + g) & 1))) * GB + lane * 16;
+            [[maybe_unused]] const unsigned char* bb_next = lds_b + (g3 == 2 ? 0 : g3 + 1) * GB + lane * 16;   // B3: group g+1's buffer
 #pragma unroll
             for (int i = 0; i < MB; ++i) { goff[i] = goff_next[i]; goff_next[i] = grp_off(g + 1, i); }   // (kd, kh) rows, in voxels
 #ifdef EXP_BGLOB
@@ -861,8 +888,10 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             const u32x4* const bgn = g < 8 ? bg + PG : wnxt;
             (void)bb;
 #else
+            if (!B3 || g == 0) {                        // (B3: the previous group read these before its barrier)
 #pragma unroll
-            for (int q = 0; q < PF; ++q) frag_b(q, q, bb);
+                for (int q = 0; q < PF; ++q) frag_b(q, q, bb);
+            }
 #endif
             static_for<NS>([&](auto sc_) {
                 constexpr int s = decltype(sc_)::value;
@@ -874,7 +903,10 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 else frag_bg(s + PFB - NS, (s + PFB) % BR, bgn);
 #else
                 if (s + PF < NS) { frag_a(s + PF, (s + PF) % R, goff); frag_b(s + PF, (s + PF) % R, bb); }
-                else if (g < 8) frag_a(s + PF - NS, (s + PF) % R, goff_next);
+                else if (g < 8) {
+                    frag_a(s + PF - NS, (s + PF) % R, goff_next);
+                    if constexpr (B3) frag_b(s + PF - NS, (s + PF) % R, bb_next);
+                }
 #endif
 #endif
 #ifdef EXP_NO_SGB
