@@ -10,7 +10,7 @@
 #include "common.h"
 
 #ifndef TAIL_MINB
-#define TAIL_MINB 1
+#define TAIL_MINB 4     // four workgroups per CU (128 registers, 36 KB LDS each): 0.404 -> 0.394 ms against three (158 registers)
 #endif
 #ifndef TAIL_RT
 #define TAIL_RT 8
