@@ -6,18 +6,19 @@
 
 namespace msnet {
 
+// CUs of the CURRENT device (cached per device ordinal: one process may drive several devices in turn)
 static inline int num_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) == hipSuccess &&
-            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
-        else n = 256;
+    static int cache[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!cache[dev]) {
+        int v = 0;
+        cache[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
 #ifdef EXP_STAMP
-        if (const char* e = getenv("MSNET_EXP_BLOCKS")) n = atoi(e);   // diagnostic: run the persistent kernels on fewer CUs
+        if (const char* e = getenv("MSNET_EXP_BLOCKS")) cache[dev] = atoi(e);   // diagnostic: run the persistent kernels on fewer CUs
 #endif
     }
-    return n;
+    return cache[dev];
 }
 
 struct ConvArgs {
