@@ -352,8 +352,11 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 dst[u] = __builtin_bit_cast(f32x4, raw);
             }
         };
-        // split + copy slots [u0, u1) of the register set `src` into LDS plane slot `pslot` (a run-time value in the sliding kernel)
-        auto write_a = [&](const f32x4 (&src)[PL], int pslot, int u0, int u1) {
+        // split + copy slots [u0, u1) of the register set `src` into LDS plane slot `pslot` (a run-time value in the sliding kernel).
+        // pre = true: the set already holds hi|lo fp16 quads (presplit below), only the two LDS stores are left.
+        auto write_a = [&](const f32x4 (&src)[PL], int pslot, int u0, int u1, auto prec) {
+            constexpr bool PRE = decltype(prec)::value;
+            struct H2 { half4 a, b; };
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
                 if (u < u0 || u >= u1) continue;
@@ -361,12 +364,12 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                     half4 hi, lo;
 #ifdef EXP_NO_SPLIT
                     {   // diagnostic: pure copy (wrong numerics) -- what the loader costs without the split VALU work
-                        struct H2 { half4 a, b; };
                         const H2 t = __builtin_bit_cast(H2, src[u]);
                         hi = t.a; lo = t.b;
                     }
 #else
-                    split4(src[u], hi, lo);
+                    if constexpr (PRE) { const H2 t = __builtin_bit_cast(H2, src[u]); hi = t.a; lo = t.b; }
+                    else split4(src[u], hi, lo);
 #endif
                     const int off = pslot * (IH * IW * RB) + ((SWZ || CPERM) ? lsw_[u] : lhi0 + u * (LT / VR) * RB);
                     *reinterpret_cast<half4*>(lds + off) = hi;
@@ -374,6 +377,21 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 }
             }
         };
+        // Stride 2: the planes that can only be copied in the b1/b2 window (they are read until the last group) are split in
+        // registers during the last groups, under the MFMAs; the window -- in which the MFMA waves wait -- then holds only their
+        // LDS stores (32->64: -2.4 %).  Measured on the stride-1 Co = 64 kernels too: +1 % (more spills), so not used there.
+        constexpr bool PRESPLIT = STRIDE == 2 && ID == 5;
+        auto presplit = [&](f32x4 (&v)[PL]) {
+            struct H2 { half4 a, b; };
+#pragma unroll
+            for (int u = 0; u < PL; ++u) {
+                half4 hi, lo;
+                split4(v[u], hi, lo);
+                v[u] = __builtin_bit_cast(f32x4, H2{hi, lo});
+            }
+        };
+        constexpr std::integral_constant<bool, false> RAW{};
+        [[maybe_unused]] constexpr std::integral_constant<bool, true> SPLIT{};
         // Weight groups form one endless stream k = it*9 + g (chunk = it % nchunks).  Group k lives in register set
         // k % PD from the moment it is requested (while group k-PD-1 is multiplied, i.e. ~PD group times = several L2
         // latencies earlier) until it is copied into LDS buffer k & 1 (while group k-1 is multiplied).
@@ -450,7 +468,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             for (int it = 0; it < nitems; ++it) {
                 MSNET_LDS_BARRIER();                    // b1
 #pragma unroll
-                for (int pl = 0; pl < ID; ++pl) write_a(av[pl], pl, 0, PL);
+                for (int pl = 0; pl < ID; ++pl) write_a(av[pl], pl, 0, PL, RAW);
                 MSNET_LDS_BARRIER();                    // b2
                 const Coord c = coord_of(nxt);
 #pragma unroll
@@ -496,8 +514,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 MSNET_LDS_BARRIER();                    // b1: MFMA waves are done with the previous tile
                 STAMP(wave, sidx, lane);
                 if (cs) {                               // (LDS copies only inside the branches)
-                    if (!early) { write_a(av[0], (2 * rot) & 3, 0, PL); write_a(av[1], (2 * rot + 1) & 3, 0, PL); }
-                    write_a(av[2], (2 * rot + 2) & 3, 0, PL); write_a(av[3], (2 * rot + 3) & 3, 0, PL);
+                    if (!early) { write_a(av[0], (2 * rot) & 3, 0, PL, RAW); write_a(av[1], (2 * rot + 1) & 3, 0, PL, RAW); }
+                    write_a(av[2], (2 * rot + 2) & 3, 0, PL, RAW); write_a(av[3], (2 * rot + 3) & 3, 0, PL, RAW);
                 }
                 MSNET_WINDOW_B(0)
                 STAMP(wave, sidx, lane);
@@ -509,15 +527,15 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 MSNET_GROUP(1, 0)
                 issue_a(av[3], nx, 3, more && !ncont, 0, PL);
                 MSNET_GROUP(2, 0)                     // g_2 passed: this item's logical plane 0 (slot 2*rot) is dead
-                write_a(av[0], 2 * rot, 0, H0);
+                write_a(av[0], 2 * rot, 0, H0, RAW);
                 MSNET_GROUP(3, 0)
-                write_a(av[0], 2 * rot, H0, H1);
+                write_a(av[0], 2 * rot, H0, H1, RAW);
                 MSNET_GROUP(4, 0)
-                write_a(av[0], 2 * rot, H1, PL);
+                write_a(av[0], 2 * rot, H1, PL, RAW);
                 MSNET_GROUP(5, 0)                     // g_5 passed: logical plane 1 (slot 2*rot + 1) is dead
-                write_a(av[1], 2 * rot + 1, 0, HH);
+                write_a(av[1], 2 * rot + 1, 0, HH, RAW);
                 MSNET_GROUP(6, 0)
-                write_a(av[1], 2 * rot + 1, HH, PL);
+                write_a(av[1], 2 * rot + 1, HH, PL, RAW);
                 MSNET_GROUP(7, 0)
                 MSNET_TAIL_B(0)
                 early = more && !ncont;
@@ -527,6 +545,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         }
         bool early = false;                             // planes 0,1 of this item already copied during the previous one
         [[maybe_unused]] int sidx = 0;
+#ifndef EXP_NO_A_STAGE
+        if constexpr (PRESPLIT) { presplit(av[2]); presplit(av[3]); presplit(av[4]); }   // first item: its window expects hi|lo quads
+#endif
         // The loader shares each SIMD with an MFMA wave and runs ~3x slower than alone, so its per-item work (28 loads,
         // 28 split+copy, 27 weight pieces) is spread evenly over the nine group slots instead of bunched at the barriers.
         constexpr int H0 = (PL + 2) / 3, H1 = (2 * PL + 2) / 3, HH = (PL + 1) / 2;
@@ -538,9 +559,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             MSNET_LDS_BARRIER();                        // b1: MFMA waves are done with the previous tile
             STAMP(wave, sidx, lane);
 #ifndef EXP_NO_A_STAGE
-            if (!early) { write_a(av[0], 0, 0, PL); write_a(av[1], 1, 0, PL); }
-            write_a(av[2], 2, 0, PL); write_a(av[3], 3, 0, PL);
-            if constexpr (ID > 4) write_a(av[4], 4, 0, PL);
+            if (!early) { write_a(av[0], 0, 0, PL, RAW); write_a(av[1], 1, 0, PL, RAW); }
+            if constexpr (PRESPLIT) { write_a(av[2], 2, 0, PL, SPLIT); write_a(av[3], 3, 0, PL, SPLIT); write_a(av[4], 4, 0, PL, SPLIT); }
+            else { write_a(av[2], 2, 0, PL, RAW); write_a(av[3], 3, 0, PL, RAW); }
 #endif
             MSNET_WINDOW_B(PAR)
             STAMP(wave, sidx, lane);
@@ -571,24 +592,27 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             MSNET_GROUP(2, PAR)                         // g_2 passed: kd = 0 groups done, plane 0 is dead
 #ifndef EXP_NO_A_STAGE
             if constexpr (SPREAD) issue_a(av[3], nx, 3, more, 0, PL);
-            write_a(av[0], 0, 0, H0);
+            write_a(av[0], 0, 0, H0, RAW);
 #endif
             MSNET_GROUP(3, PAR)
 #ifndef EXP_NO_A_STAGE
             if constexpr (SPREAD) issue_a(av[4], nx, 4, more, 0, PL);
-            write_a(av[0], 0, H0, H1);
+            write_a(av[0], 0, H0, H1, RAW);
 #endif
             MSNET_GROUP(4, PAR)
 #ifndef EXP_NO_A_STAGE
-            write_a(av[0], 0, H1, PL);
+            write_a(av[0], 0, H1, PL, RAW);
+            if constexpr (PRESPLIT) presplit(av[2]);
 #endif
             MSNET_GROUP(5, PAR)                         // g_5 passed: kd = 1 groups done, plane 1 is dead
 #ifndef EXP_NO_A_STAGE
-            write_a(av[1], 1, 0, HH);
+            write_a(av[1], 1, 0, HH, RAW);
+            if constexpr (PRESPLIT) presplit(av[3]);
 #endif
             MSNET_GROUP(6, PAR)
 #ifndef EXP_NO_A_STAGE
-            write_a(av[1], 1, HH, PL);
+            write_a(av[1], 1, HH, PL, RAW);
+            if constexpr (PRESPLIT) presplit(av[4]);
 #endif
             MSNET_GROUP(7, PAR)
             MSNET_TAIL_B(PAR)
@@ -1444,6 +1468,9 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(Co
         dhw_[u] = slot < NSLOT ? ((id << 16) | (ih << 8) | iw) : -1;
     }
     TileCtr ctr, nxt;                                    // current item / the one being fetched
+    // (Tile order: w fastest, d slowest.  The counters show 1.02 GB of HBM reads for the 0.40 GB input -- the two input planes
+    // d-neighbours share are re-fetched a thousand tiles later -- but making d the fastest or the second digit changed nothing
+    // in the network (0.65 ms either way) and cost 5 % in the layer bench with d fastest: the 1.6 GB of stores set the time.)
     ctr.init(lb, G, 1, a.ntw, a.nth, a.ntd, 1);
     nxt = ctr;
     auto issue_a = [&](const TileCtr& c) {
