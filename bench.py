@@ -180,6 +180,9 @@ def main():
     ap.add_argument("--precision", default="split-fp16", choices=["split-fp16", "fp32"])
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-launch HIP events (diagnostic)")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the aggregator forward from a captured HIP graph (module.use_graph); its launches then carry no "
+                         "HIP events, so the roofline of the dominant kernel is not measured in such a run -- diagnostic, not the default")
     args = ap.parse_args()
 
     import msnets_amd
@@ -218,6 +221,8 @@ def main():
         vol = torch.empty((B, 8, nd, hh, wh), device=dev, dtype=torch.float32)
         if args.no_volume:
             vol.copy_(synthetic.random_volume(tuple(vol.shape), seed=rank).to(dev))
+
+    model.use_graph = bool(args.graph)
 
     def local_step():
         if not args.no_volume:
@@ -305,7 +310,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": desc + ", batch=%d per GPU" % B, "global_batch": n_total,
                        "parallelism": "dp%d (rank-sharded pairs, RCCL all-gather of disparity maps)" % world,
-                       "includes_volume_build": not args.no_volume,
+                       "includes_volume_build": not args.no_volume, "hip_graph": bool(args.graph),
                        "collective": ("rccl all_gather_into_tensor" if torch.distributed.is_available() and
                                       torch.distributed.is_initialized() else "none (single process)")},
             "step_ms": {"median": pct(50), "p10": pct(10), "p90": pct(90), "source": "HIP events between steps, rank 0"},

@@ -77,6 +77,7 @@ class GCNet_CostVolumeAggre(nn.Module):
         self._guard = None
         self._arena = hipops.Arena()      # activation buffers reused across forwards (hipops.Arena)
         self._use_arena = True
+        self.use_graph = False            # True: forwards are captured as HIP graphs per input buffer (hipops._graphed_forward)
 
     # ---- device constants ------------------------------------------------------------------------
     def invalidate_plans(self):
@@ -112,7 +113,8 @@ class GCNet_CostVolumeAggre(nn.Module):
         if cv.dim() != 5:
             raise ValueError("cv must be [N,C,D,H,W]")
         self._use_arena = taps is None          # tapped activations are handed to the caller: fresh tensors
-        return hipops.guarded_forward(self, lambda precision: self._forward(cv, taps, precision))
+        return hipops.guarded_forward(self, lambda precision: self._forward(cv, taps, precision),
+                                      graph_key=(cv.data_ptr(), tuple(cv.shape)) if taps is None else None)
 
     def _forward(self, cv, taps, precision):
         pl = self._plans(precision)

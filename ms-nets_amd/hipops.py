@@ -240,17 +240,21 @@ class exact_tails:
         return False
 
 
-def guarded_forward(module, run):
+def guarded_forward(module, run, graph_key=None):
     """Shared by the two aggregators.  run(precision) -> output.  On the split-fp16 path the forward runs under a
     RangeGuard; if an activation (or the input) left the fp16 range the result is discarded, a warning is issued and the
     forward is repeated on the exact fp32-input MFMA kernels with fp32 tails -- and the module stays there (sticky until
-    invalidate_plans()), so a checkpoint with large activations costs the sync and the double forward once."""
+    invalidate_plans()), so a checkpoint with large activations costs the sync and the double forward once.
+    graph_key (input address, shapes): with module.use_graph set, the forward is captured once per key as a HIP graph and
+    replayed afterwards (_graphed_forward)."""
     precision = module._forced_precision or _default_precision
     run_ = run
 
     def run(prec):                      # activations come from the module's arena (not when taps are handed out)
         with use_arena(module._arena if module._use_arena else None):
             return run_(prec)
+    if graph_key is not None and getattr(module, "use_graph", False) and module._use_arena:
+        return _graphed_forward(module, run_, graph_key)
     if precision != "split-fp16":
         with exact_tails():
             return run(precision)
@@ -268,6 +272,62 @@ def guarded_forward(module, run):
         with exact_tails():
             out = run("fp32")
     return out
+
+
+MAX_GRAPHS_PER_MODULE = 4
+
+
+def _graphed_forward(module, run, graph_key):
+    """module.use_graph = True: the ~45 launches of a forward (and their host work: ctypes calls, shape checks, buffer
+    look-ups) become one hipGraphLaunch.  A graph is tied to the input's ADDRESS and shape, the precision and the parameter
+    state (state_key: the check the eager path makes too), so it pays in loops that reuse their input buffer -- a serving
+    loop, bench.py --graph; up to MAX_GRAPHS_PER_MODULE keys are kept.  The first call per key runs eagerly (plans, arena,
+    range fallback), the second captures.  The range guard stays on: its flag is cleared inside the graph and read after the
+    replay; a trip drops the graphs and repeats the forward eagerly on fp32.  Returns a copy of the graph's output buffer."""
+    graphs = module.__dict__.setdefault("_graphs", {})
+    precision = module._forced_precision or _default_precision
+    key = tuple(graph_key) + (precision, state_key(module))
+    g = graphs.get(key)
+    if g is None:
+        module.use_graph = False
+        try:
+            out = guarded_forward(module, run)          # eager: builds plans and arena, settles the precision
+        finally:
+            module.use_graph = True
+        if (module._forced_precision or _default_precision) == precision:      # (else: the range guard moved the module to fp32)
+            if len(graphs) >= MAX_GRAPHS_PER_MODULE:
+                graphs.pop(next(iter(graphs)))
+            graphs[key] = {"graph": None}               # captured on the next call with this key
+        return out
+    if g["graph"] is None:
+        dev = next(module.parameters()).device
+        guard = RangeGuard(dev) if precision == "split-fp16" and module.range_check else None
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            if guard is not None:
+                guard.__enter__()
+            try:
+                with use_arena(module._arena):
+                    if precision != "split-fp16":
+                        with exact_tails():
+                            out = run(precision)
+                    else:
+                        out = run(precision)
+            finally:
+                if guard is not None:
+                    guard.__exit__()
+        g.update(graph=graph, out=out, guard=guard)
+    g["graph"].replay()
+    if g["guard"] is not None and g["guard"].tripped():
+        graphs.clear()
+        module.use_graph = False
+        try:
+            return guarded_forward(module, run)         # warns, repeats on fp32, makes that sticky
+        finally:
+            module.use_graph = True
+    out = g["out"]
+    return tuple(t.clone() for t in out) if isinstance(out, tuple) else out.clone()
 
 
 class ConvBNPlan:

@@ -71,6 +71,7 @@ class PSMNet_CostVolumeAggre(nn.Module):
         self._guard = None
         self._arena = hipops.Arena()      # activation buffers reused across forwards (hipops.Arena)
         self._use_arena = True
+        self.use_graph = False            # True: forwards are captured as HIP graphs per input buffer (hipops._graphed_forward)
 
     def invalidate_plans(self):
         """Drop the packed weights / folded BN constants; the next forward rebuilds them from the current parameters.
@@ -159,7 +160,7 @@ class PSMNet_CostVolumeAggre(nn.Module):
                 _, _, cost3 = self._trunk(cost, taps, precision)
                 return hipops.trilinear_softargmin(cost3, (self.maxdisp, H, W))
         self._use_arena = taps is None           # tapped activations are handed to the caller: fresh tensors
-        return hipops.guarded_forward(self, run)
+        return hipops.guarded_forward(self, run, graph_key=(cost.data_ptr(), tuple(cost.shape), H, W) if taps is None else None)
 
     def forward_all_heads(self, cost, out_hw=None):
         """(pred1, pred2, pred3) as the reference's training-mode return (psmnet_3dcnn.py:149-177)."""

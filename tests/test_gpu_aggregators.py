@@ -664,3 +664,48 @@ def test_errors(gpu):
         m(torch.rand(1, 8, 32, 16, 32).cuda())          # 2*D' != maxdisp  (gcnet_3dcnn.py:135)
     with pytest.raises(ValueError):
         P(32).eval().cuda()(torch.rand(1, 8, 8, 16, 16).cuda())
+
+
+def test_graphed_forward_equals_eager(gpu):
+    """module.use_graph: the forward replayed from a captured HIP graph returns the bits of the eager forward, follows the
+    CONTENT of the (reused) input buffer, and a new input buffer gets its own capture."""
+    from msnets_amd import hipops
+    from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre
+    from msnets_amd.psmnet_3dcnn import PSMNet_CostVolumeAggre
+    torch.manual_seed(3)
+    for model, shape in ((GCNet_CostVolumeAggre(32).eval().cuda(), (1, 8, 16, 32, 48)),
+                         (PSMNet_CostVolumeAggre(32).eval().cuda(), (1, 64, 8, 12, 20))):
+        x = torch.rand(shape, device="cuda")
+        ref1 = model(x).clone()
+        x2 = torch.rand(shape, device="cuda")
+        ref2 = model(x2).clone()
+        model.use_graph = True
+        buf = x.clone()
+        outs = [model(buf) for _ in range(3)]                      # eager, capture + replay, replay
+        assert all(torch.equal(o, ref1) for o in outs)
+        assert len(model._graphs) == 1 and next(iter(model._graphs.values()))["graph"] is not None
+        buf.copy_(x2)
+        assert torch.equal(model(buf), ref2)                       # same buffer, new content
+        other = x.clone()
+        assert torch.equal(model(other), ref1) and torch.equal(model(other), ref1) and len(model._graphs) == 2
+        kept = model(buf)
+        model(other)
+        assert torch.equal(kept, ref2)                             # returned tensors are copies, not the graph's buffer
+
+
+def test_graphed_forward_range_guard(gpu):
+    """The fp16-range guard stays armed under graph replay: an out-of-range input trips it after the replay, the graphs are
+    dropped and the forward is repeated on the fp32 kernels."""
+    from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre
+    torch.manual_seed(4)
+    model = GCNet_CostVolumeAggre(32).eval().cuda()
+    x = torch.rand((1, 8, 16, 32, 48), device="cuda")
+    model.use_graph = True
+    a = model(x); b = model(x); c = model(x)
+    assert torch.equal(a, b) and torch.equal(b, c)
+    x[0, 0, 0, 0, 0] = 1e5
+    with pytest.warns(RuntimeWarning, match="fp16 range"):
+        y = model(x)
+    assert bool(torch.isfinite(y).all()) and model._forced_precision == "fp32" and not model._graphs
+    model.use_graph = False
+    assert torch.allclose(y, model(x), atol=0, rtol=0)
