@@ -79,6 +79,7 @@ class PSMNet_CostVolumeAggre(nn.Module):
         self._plan = None
         self._plan_key = None
         self._forced_precision = None
+        self.__dict__.pop("_graphs", None)        # captured HIP graphs hold the old packed weights
 
     def _plans(self, precision):
         key = hipops.state_key(self) + (precision,)
