@@ -1785,7 +1785,7 @@ static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
 
 // Sliding-window launch for single-chunk stride-1 layers.  A tile column (all d at one (h, w) tile) is cut into `nseg`
 // segments that are dealt to the persistent workgroups; within a segment every tile after the first stages two planes
-// instead of four (measured: 0.9 of a tile's time), so longer segments are cheaper per tile but balance worse.  Returns -1
+// instead of four (measured: 0.85 of a tile's time), so longer segments are cheaper per tile but balance worse.  Returns -1
 // when plain tiles are estimated to be no slower (the caller then launches the ordinary kernel).
 template <int TH, int TW, int MB, int NB>
 static int launch_f16s_slide(const char* name, ConvArgs a, hipStream_t s) {
@@ -1797,14 +1797,15 @@ static int launch_f16s_slide(const char* name, ConvArgs a, hipStream_t s) {
     if ((size_t)a.OD * a.OH * a.OW * a.Co * 4 > 0xfffffff0u || (size_t)a.D * a.H * a.W * a.Ci * 4 > 0x7ffffff0u)
         return -1;                                      // 32-bit offsets inside a sample (drained stores, loader descriptor)
     const double G = (double)num_cus();
-    double best = ceil((double)cols * a.ntd / G);       // plain tiles, one unit of time each
+    const double plain = ceil((double)cols * a.ntd / G);    // plain tiles, one unit of time each
+    double best = plain;
     int best_seg = 0;
-    for (int seg = 1; seg <= a.ntd; ++seg) {
+    for (int seg = 1; seg <= a.ntd; ++seg) {            // cheapest segmentation; it must beat plain tiles by 3 % to be used
         if (a.ntd % seg) continue;
         const int len = a.ntd / seg;
         if (len < 2) break;
-        const double cost = ceil((double)cols * seg / G) * (1.0 + 0.9 * (len - 1));
-        if (cost < 0.97 * best) { best = cost; best_seg = seg; }
+        const double cost = ceil((double)cols * seg / G) * (1.0 + 0.85 * (len - 1));    // (0.85: measured on 48x136x240 and 96x272x480)
+        if (cost < best && cost < 0.97 * plain) { best = cost; best_seg = seg; }
     }
     if (const char* e = getenv("MSNET_FORCE_SLIDE_SEG")) {     // test hook: force the sliding kernel with this many segments
         const int seg = atoi(e);

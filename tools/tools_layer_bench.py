@@ -11,6 +11,7 @@ LAYERS = {
     # name: (kind, Ci, Co, stride, (D,H,W) input, residual)
     "c8":        ("conv", 8, 32, 1, (96, 272, 480), False),
     "s1_32_32":  ("conv", 32, 32, 1, (96, 272, 480), False),
+    "s1_32_32q": ("conv", 32, 32, 1, (48, 136, 240), False),      # PSMNet's 32->32 layers (quarter resolution)
     "s2_32_64":  ("conv", 32, 64, 2, (96, 272, 480), False),
     "s2_16_64":  ("conv", 16, 64, 2, (96, 272, 480), False),     # (not a network layer: stride-2 staging with full-line requests)
     "s1_64_64":  ("conv", 64, 64, 1, (48, 136, 240), False),
