@@ -45,12 +45,10 @@ def _stale(target, deps):
 
 def build(force=False, verbose=True, defines=(), lib=None):
     """defines/lib: build an experiment variant (-D flags) into another .so without touching the shipped one."""
-    global LIB
     hipcc = _hipcc()
     tag = "" if not defines else "_" + "_".join(d.replace("=", "") for d in defines)
     objdir = os.path.join(HERE, "build" + tag)
-    if lib:
-        LIB = lib
+    out = lib or LIB                                   # (a variant's path must not stick to later default builds)
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(HERE, "..", "include", "msnet_hip.h"),
                os.path.abspath(__file__)]
@@ -68,12 +66,12 @@ def build(force=False, verbose=True, defines=(), lib=None):
     failed = [s for s, p in procs if p.wait() != 0]
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
-    if force or procs or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", LIB] + objs
+    if force or procs or _stale(out, objs):
+        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", out] + objs
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-    return LIB
+    return out
 
 
 if __name__ == "__main__":

@@ -344,6 +344,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 mask &= mask0;
             }
             mask = plane_ok ? mask : 0u;
+#ifdef EXP_NO_A_LOAD
+            if (STRIDE == 2) mask = 0u;                 // diagnostic (wrong numerics): requests go out dead, no memory traffic
+#endif
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
                 if (u < u0 || u >= u1) continue;
@@ -360,6 +363,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #pragma unroll
             for (int u = 0; u < PL; ++u) {
                 if (u < u0 || u >= u1) continue;
+#ifdef EXP_NO_A_WRITE
+                if (STRIDE == 2) continue;              // diagnostic (wrong numerics): no split, no LDS copy
+#endif
                 if (u * LT + lt < PSLOT) {
                     half4 hi, lo;
 #ifdef EXP_NO_SPLIT
@@ -405,6 +411,11 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         int bi_[3];
 #pragma unroll
         for (int u = 0; u < 3; ++u) bi_[u] = (PG % LT == 0 || u * LT + lt < PG) ? u * LT + lt : PG - 1;
+#ifdef EXP_HALF_B
+        constexpr bool EXP_HALF_B_ON = STRIDE == 2;     // diagnostic (wrong numerics): half the stride-2 weight stream
+#else
+        constexpr bool EXP_HALF_B_ON = false;
+#endif
 #ifdef EXP_BGLOB
 #define MSNET_ISSUE_B(K, SET) do { (void)(SET); } while (0)
 #define MSNET_WRITE_B(K, SET) do { (void)(SET); } while (0)
@@ -412,14 +423,14 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #define MSNET_ISSUE_B(K, SET)                                                                                      \
     do {                                                                                                           \
         const u32x4* src_ = b_src((K) - k0);                                                                       \
-        SET.v0 = src_[bi_[0]]; SET.v1 = src_[bi_[1]];                                                              \
+        SET.v0 = src_[bi_[0]]; if (!EXP_HALF_B_ON) SET.v1 = src_[bi_[1]];                                          \
         if constexpr (NLB > 2) SET.v2 = src_[bi_[2]];                                                              \
         if constexpr (NLB > 3) { SET.v3 = src_[3 * LT + lt]; SET.v4 = src_[4 * LT + lt]; SET.v5 = src_[5 * LT + lt]; }    \
     } while (0)
 #define MSNET_WRITE_B(K, SET)                                                                                      \
     do {                                                                                                           \
         u32x4* dst_ = reinterpret_cast<u32x4*>(lds_b + (B3 ? ((K) - k0) % 3 : ((K) & 1)) * GB);                    \
-        dst_[bi_[0]] = SET.v0; dst_[bi_[1]] = SET.v1;                                                              \
+        dst_[bi_[0]] = SET.v0; if (!EXP_HALF_B_ON) dst_[bi_[1]] = SET.v1;                                          \
         if constexpr (NLB > 2) dst_[bi_[2]] = SET.v2;                                                              \
         if constexpr (NLB > 3) { dst_[3 * LT + lt] = SET.v3; dst_[4 * LT + lt] = SET.v4; dst_[5 * LT + lt] = SET.v5; }    \
     } while (0)
@@ -571,51 +582,74 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             // The next tile is requested during groups 0-2; its planes 0 / 1 are copied as soon as they are dead.  (Past the
             // last item the requests are dead -- `more` = false -- and the copies put zeros into planes nobody reads again.)
             const Coord nx = coord_of(nxt);
-            // Stride 2 (five planes, 104 KB per item and CU next to a weight stream of the same size): one plane per group over
-            // groups 0-4 instead of everything in groups 0-2 -- the per-wave stamps showed single buffer loads taking 300-500
-            // cycles to ISSUE in that burst (the CU's outstanding-request capacity), which the MFMA waves then sat out at g_0-g_2.
+            // Stride 2 (five planes, 104 KB per item and CU): the next tile's requests go out evenly over all eight slots, SPS per
+            // thread and slot.  What limits this kernel is the rate at which a CU can take in lines that miss its L1 -- ~12 B/clk,
+            // i.e. ~13 KB per group: with everything in groups 0-2 (or a plane per group in 0-4) single buffer loads took
+            // 300-500 cycles to ISSUE, the loader waves reached the group barriers late and the MFMA waves sat there; a
+            // probe (-DEXP_LAT_PROBE) shows the data back ~400 cycles after the last request of a slot has been accepted.
             constexpr bool SPREAD = ID > 4;
+            constexpr int SPS = SPREAD ? (ID * PL + 7) / 8 : 0;
+            [[maybe_unused]] auto issue_seq = [&](auto slotc) {     // requests [slot*SPS, slot*SPS + SPS) of the plane-major sequence
+                constexpr int k0 = decltype(slotc)::value * SPS;
+                static_for<SPS>([&](auto kc) {
+                    constexpr int k = k0 + decltype(kc)::value;
+                    if constexpr (k < ID * PL) issue_a(av[k / PL], nx, k / PL, more, k % PL, k % PL + 1);
+                });
+            };
+#define MSNET_SEQ(S) issue_seq(std::integral_constant<int, S>{})
 #ifndef EXP_NO_A_STAGE
-            if constexpr (SPREAD) issue_a(av[0], nx, 0, more, 0, PL);
+            if constexpr (SPREAD) MSNET_SEQ(0);
             else { issue_a(av[0], nx, 0, more, 0, PL); issue_a(av[1], nx, 1, more, 0, HH); }
+#endif
+#ifdef EXP_LAT_PROBE
+            // diagnostic: how long until the requests just issued (and everything older) have returned
+            STAMP(wave, sidx, lane);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(wave, sidx, lane);
 #endif
             MSNET_GROUP(0, PAR)
 #ifndef EXP_NO_A_STAGE
-            if constexpr (SPREAD) issue_a(av[1], nx, 1, more, 0, PL);
+            if constexpr (SPREAD) MSNET_SEQ(1);
             else { issue_a(av[1], nx, 1, more, HH, PL); issue_a(av[2], nx, 2, more, 0, PL); }
 #endif
             MSNET_GROUP(1, PAR)
 #ifndef EXP_NO_A_STAGE
-            if constexpr (SPREAD) issue_a(av[2], nx, 2, more, 0, PL);
+            if constexpr (SPREAD) MSNET_SEQ(2);
             else issue_a(av[3], nx, 3, more, 0, PL);
 #endif
             MSNET_GROUP(2, PAR)                         // g_2 passed: kd = 0 groups done, plane 0 is dead
 #ifndef EXP_NO_A_STAGE
-            if constexpr (SPREAD) issue_a(av[3], nx, 3, more, 0, PL);
+            if constexpr (SPREAD) MSNET_SEQ(3);
             write_a(av[0], 0, 0, H0, RAW);
 #endif
             MSNET_GROUP(3, PAR)
 #ifndef EXP_NO_A_STAGE
-            if constexpr (SPREAD) issue_a(av[4], nx, 4, more, 0, PL);
+            if constexpr (SPREAD) MSNET_SEQ(4);
             write_a(av[0], 0, H0, H1, RAW);
 #endif
             MSNET_GROUP(4, PAR)
 #ifndef EXP_NO_A_STAGE
+            if constexpr (SPREAD) MSNET_SEQ(5);
             write_a(av[0], 0, H1, PL, RAW);
-            if constexpr (PRESPLIT) presplit(av[2]);
 #endif
             MSNET_GROUP(5, PAR)                         // g_5 passed: kd = 1 groups done, plane 1 is dead
 #ifndef EXP_NO_A_STAGE
+            if constexpr (SPREAD) MSNET_SEQ(6);
             write_a(av[1], 1, 0, HH, RAW);
-            if constexpr (PRESPLIT) presplit(av[3]);
+            if constexpr (PRESPLIT) presplit(av[2]);
 #endif
             MSNET_GROUP(6, PAR)
 #ifndef EXP_NO_A_STAGE
+            if constexpr (SPREAD) MSNET_SEQ(7);
             write_a(av[1], 1, HH, PL, RAW);
-            if constexpr (PRESPLIT) presplit(av[4]);
+            if constexpr (PRESPLIT) presplit(av[3]);
 #endif
             MSNET_GROUP(7, PAR)
+#undef MSNET_SEQ
             MSNET_TAIL_B(PAR)
+#ifndef EXP_NO_A_STAGE
+            if constexpr (PRESPLIT) presplit(av[4]);    // (its last request went out in slot 7: split behind g_7, before b1)
+#endif
             early = more;
             cur = nxt; nxt.next();
         };
