@@ -1502,9 +1502,9 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(Co
         dhw_[u] = slot < NSLOT ? ((id << 16) | (ih << 8) | iw) : -1;
     }
     TileCtr ctr, nxt;                                    // current item / the one being fetched
-    // (Tile order: w fastest, d slowest.  The counters show 1.02 GB of HBM reads for the 0.40 GB input -- the two input planes
-    // d-neighbours share are re-fetched a thousand tiles later -- but making d the fastest or the second digit changed nothing
-    // in the network (0.65 ms either way) and cost 5 % in the layer bench with d fastest: the 1.6 GB of stores set the time.)
+    // (Tile order: w fastest, d slowest.  FETCH_SIZE reports 0.76-1.0 GB per launch for the 0.40 GB input: the two input planes
+    // d-neighbours share come back over the fabric a thousand tiles later (Infinity Cache, not necessarily HBM).  Making d the
+    // fastest or the second digit was measured with counters: 0.95 GB and 2-3 % slower either way -- the order stays.)
     ctr.init(lb, G, 1, a.ntw, a.nth, a.ntd, 1);
     nxt = ctr;
     auto issue_a = [&](const TileCtr& c) {
