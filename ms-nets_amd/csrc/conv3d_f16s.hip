@@ -938,7 +938,14 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         auto do_group = [&](int g, auto drain) {
             const int g3 = g - 3 * ((g * 11) >> 5);     // g % 3 (g < 9)
             const unsigned char* bb = lds_b + (RESB ? g : (B3 ? g3 : ((gg0 + g) & 1))) * GB + lane * 16;
+#ifdef EXP_B_EARLY
+            constexpr bool BEARLY = true;               // diagnostic (wrong numerics): every kernel reads the next group's first B
+            [[maybe_unused]] const unsigned char* bb_next =   // fragments before the barrier -- what a third buffer would buy in time
+                lds_b + (B3 ? (g3 == 2 ? 0 : g3 + 1) : ((gg0 + g + 1) & 1)) * GB + lane * 16;
+#else
+            constexpr bool BEARLY = B3;
             [[maybe_unused]] const unsigned char* bb_next = lds_b + (g3 == 2 ? 0 : g3 + 1) * GB + lane * 16;   // B3: group g+1's buffer
+#endif
 #pragma unroll
             for (int i = 0; i < MB; ++i) { goff[i] = goff_next[i]; goff_next[i] = grp_off(g + 1, i); }   // (kd, kh) rows, in voxels
 #ifdef EXP_BGLOB
@@ -946,7 +953,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             const u32x4* const bgn = g < 8 ? bg + PG : wnxt;
             (void)bb;
 #else
-            if (!B3 || g == 0) {                        // (B3: the previous group read these before its barrier)
+            if (!BEARLY || g == 0) {                    // (B3: the previous group read these before its barrier)
 #pragma unroll
                 for (int q = 0; q < PF; ++q) frag_b(q, q, bb);
             }
@@ -963,7 +970,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 if (s + PF < NS) { frag_a(s + PF, (s + PF) % R, goff); frag_b(s + PF, (s + PF) % R, bb); }
                 else if (g < 8) {
                     frag_a(s + PF - NS, (s + PF) % R, goff_next);
-                    if constexpr (B3) frag_b(s + PF - NS, (s + PF) % R, bb_next);
+                    if constexpr (BEARLY) frag_b(s + PF - NS, (s + PF) % R, bb_next);
                 }
 #endif
 #endif
