@@ -46,6 +46,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef S2_LOADER_WAVES
 #define S2_LOADER_WAVES 8
 #endif
+#ifndef MSNET_A_AUX
+#define MSNET_A_AUX 0           // cache-policy bits of the loaders' tile requests (2 = nt, measured: see DESIGN.md 4.1d)
+#endif
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // first-class vector (HIP's uint4 is a class)
@@ -351,7 +354,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             for (int u = 0; u < PL; ++u) {
                 if (u < u0 || u >= u1) continue;
                 const unsigned voff = ((mask >> u) & 1u) ? base + goff_[u] : 0xffffffffu;
-                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0);
+                const u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, MSNET_A_AUX);
                 dst[u] = __builtin_bit_cast(f32x4, raw);
             }
         };
