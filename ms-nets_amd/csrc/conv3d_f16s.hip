@@ -347,6 +347,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 mask &= mask0;
             }
             mask = plane_ok ? mask : 0u;
+#ifdef EXP_NO_PLANE0
+            if (STRIDE == 2 && pl == 0) mask = 0u;      // diagnostic (wrong numerics): what a d-sliding window would save in requests
+#endif
 #ifdef EXP_NO_A_LOAD
             if (STRIDE == 2) mask = 0u;                 // diagnostic (wrong numerics): requests go out dead, no memory traffic
 #endif
