@@ -1516,8 +1516,11 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(Co
     }
     TileCtr ctr, nxt;                                    // current item / the one being fetched
     // (Tile order: w fastest, d slowest.  FETCH_SIZE reports 0.76-1.0 GB per launch for the 0.40 GB input: the two input planes
-    // d-neighbours share come back over the fabric a thousand tiles later (Infinity Cache, not necessarily HBM).  Making d the
-    // fastest or the second digit was measured with counters: 0.95 GB and 2-3 % slower either way -- the order stays.)
+    // d-neighbours share come back over the fabric a thousand tiles later (Infinity Cache, not necessarily HBM).  Measured
+    // alternatives, all slower: d as the fastest or second tile digit (0.95 GB fetched, +2-3 %); a sliding window along d as in
+    // the 32->32 kernel (two new planes per tile, bit-identical results, +6 %) -- both scatter the 1.6 GB of stores, which adjacent
+    // workgroups otherwise write as contiguous rows; the requests spread between the K-steps instead of one burst (+-0).
+    // Ablations on the layer bench (0.89 ms): requests sent dead 0.59 ms, one store in sixteen 0.72 ms.)
     ctr.init(lb, G, 1, a.ntw, a.nth, a.ntd, 1);
     nxt = ctr;
     auto issue_a = [&](const TileCtr& c) {
