@@ -211,6 +211,15 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     // group g is multiplied, so group g+1 has been in LDS since barrier g_(g-1) and its first B fragments are read BEFORE
     // barrier g_g, like the A fragments -- with two buffers every group started with an exposed LDS round trip behind its barrier.
     constexpr bool B3 = !RESB && STRIDE == 1 && NB == 1 && NPOS * RB + 3 * GB <= 160 * 1024;
+    // KHS (the Co = 32 kernels: 1x32-voxel M-blocks, a wave's two M-blocks are adjacent h rows): weight groups are (kd, kw)
+    // COLUMNS of the 3x3x3 stencil instead of (kd, kh) rows.  M-block 0 at tap row kh+1 reads the LDS row M-block 1 reads at kh,
+    // so a 16-channel step loads four A rows once (8 ds_read_b128) and uses them for 3 kh x 2 M-blocks: 28 fragment reads per
+    // 36 MFMAs instead of 36.  The packed weight image is unchanged; the loaders pick each group's three taps out of it.
+#ifdef EXP_NO_KHS
+    constexpr bool KHS = false;
+#else
+    constexpr bool KHS = B3 && KS == 2 && MB == 2 && BW == 32 && !SWZ && (TH / (32 / BW)) % 2 == 0 && LW == 4;
+#endif
     constexpr int NBUF = RESB ? 9 : (B3 ? 3 : 2);
     static_assert(NPOS * RB + NBUF * GB <= 160 * 1024, "LDS budget");
     __shared__ __attribute__((aligned(16))) unsigned char lds[NPOS * RB + NBUF * GB];
@@ -426,9 +435,16 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #define MSNET_ISSUE_B(K, SET) do { (void)(SET); } while (0)
 #define MSNET_WRITE_B(K, SET) do { (void)(SET); } while (0)
 #else
-#define MSNET_ISSUE_B(K, SET)                                                                                      \
+// J: group index RELATIVE to the current item's first group (a compile-time constant at every call site)
+#define MSNET_ISSUE_B(J, SET)                                                                                      \
     do {                                                                                                           \
-        const u32x4* src_ = b_src((K) - k0);                                                                       \
+        if constexpr (KHS) {    /* group j = (kd, kw): piece u of a thread is tap kh = u (256 pieces a tap) */     \
+            constexpr int j_ = (J) < 9 ? (J) : (J) - 9;                                                            \
+            const u32x4* base_ = b_src((J) < 9 ? 0 : 9) + (size_t)(((j_ / 3) * 9 + j_ % 3) * 256) + lt;            \
+            SET.v0 = base_[0]; SET.v1 = base_[3 * 256]; SET.v2 = base_[6 * 256];                                   \
+            break;                                                                                                 \
+        }                                                                                                          \
+        const u32x4* src_ = b_src(J);                                                                              \
         SET.v0 = src_[bi_[0]]; if (!EXP_HALF_B_ON) SET.v1 = src_[bi_[1]];                                          \
         if constexpr (NLB > 2) SET.v2 = src_[bi_[2]];                                                              \
         if constexpr (NLB > 3) { SET.v3 = src_[3 * LT + lt]; SET.v4 = src_[4 * LT + lt]; SET.v5 = src_[5 * LT + lt]; }    \
@@ -445,26 +461,26 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 // slot of group G: copy group G + BA (BA = 2 with three LDS buffers, else 1) and request the group NSETS later into the freed set
 #define MSNET_GROUP(G, PAR)                                                         \
     MSNET_WRITE_B(k0 + (G) + BA, bw[MSNET_SETI((G) + BA, PAR)]);                    \
-    MSNET_ISSUE_B(k0 + (G) + BA + NSETS, bw[MSNET_SETI((G) + BA, PAR)]);            \
+    MSNET_ISSUE_B((G) + BA + NSETS, bw[MSNET_SETI((G) + BA, PAR)]);                 \
     STAMP(wave, sidx, lane);                                                        \
     MSNET_LDS_BARRIER();                                                            \
     STAMP(wave, sidx, lane);
 #else
 #define MSNET_GROUP(G, PAR)                                                         \
     MSNET_WRITE_B(k0 + (G) + BA, bw[MSNET_SETI((G) + BA, PAR)]);                    \
-    MSNET_ISSUE_B(k0 + (G) + BA + NSETS, bw[MSNET_SETI((G) + BA, PAR)]);
+    MSNET_ISSUE_B((G) + BA + NSETS, bw[MSNET_SETI((G) + BA, PAR)]);
 #endif
 // b1/b2 window: two buffers -- group 0 of the item; three -- nothing (groups 0, 1 were copied during the previous item)
 #define MSNET_WINDOW_B(PAR)                                                         \
     if constexpr (!B3) {                                                            \
         MSNET_WRITE_B(k0, bw[MSNET_SETI(0, PAR)]);                                  \
-        MSNET_ISSUE_B(k0 + NSETS, bw[MSNET_SETI(0, PAR)]);                          \
+        MSNET_ISSUE_B(NSETS, bw[MSNET_SETI(0, PAR)]);                               \
     }
 // behind g_7 (three buffers only): the next item's group 1 goes into the buffer group 7 has just released
 #define MSNET_TAIL_B(PAR)                                                           \
     if constexpr (B3) {                                                             \
         MSNET_WRITE_B(k0 + 10, bw[MSNET_SETI(10, PAR)]);                            \
-        MSNET_ISSUE_B(k0 + 10 + NSETS, bw[MSNET_SETI(10, PAR)]);                    \
+        MSNET_ISSUE_B(10 + NSETS, bw[MSNET_SETI(10, PAR)]);                         \
     }
 
         if constexpr (RESB) {
@@ -891,6 +907,86 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #pragma unroll
                     for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
         }
+        if constexpr (KHS) {
+            // ---- (kd, kw) column groups, A rows shared between the wave's two M-blocks (see KHS above) ----
+            // step q = ((g*2 + ks)*3 + kh): super-step S = g*2 + ks holds rows k = 0..3 (input rows bh0 + k at column offset kw,
+            // 16 channels) in row set S & 1; M-block i multiplies row kh + i with the weights of tap (kd, kh, kw).
+            static_assert(NB == 1 && KS == 2 && MB == 2, "KHS shapes");
+            int pofs[3];                                // voxel offset of the lane's output-depth plane for kd = 0..2
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd)
+                pofs[kd] = SLIDE ? ((((wm * MB) / (MW * MH) + kd + 2 * rot) & 3) * IH) * IW : kd * IH * IW;
+            const unsigned char* const arow0 = lds + vox0[0] * RB + 16 * hh;
+            half8 rh[2][4], rl[2][4], qh[3], ql[3];
+            auto ld_row = [&](auto setc, auto kc, auto gc, auto ksc) {
+                constexpr int set = decltype(setc)::value, k = decltype(kc)::value, g = decltype(gc)::value, ks = decltype(ksc)::value;
+                const unsigned char* p_ = arow0 + (pofs[g / 3] + k * IW + g % 3) * RB + ks * 32;
+                rh[set][k] = *reinterpret_cast<const half8*>(p_);
+                rl[set][k] = *reinterpret_cast<const half8*>(p_ + HB);
+            };
+            auto ld_b = [&](auto qc) {                  // B fragments of step q into ring slot q % 3
+                constexpr int q = decltype(qc)::value, g = q / 6, ks = (q / 3) % 2, kh = q % 3;
+                const unsigned char* p_ = lds_b + (g % 3) * GB + lane * 16 + ((kh * KS + ks) * NB) * 2 * 1024;
+                qh[q % 3] = *reinterpret_cast<const half8*>(p_);
+                ql[q % 3] = *reinterpret_cast<const half8*>(p_ + 1024);
+            };
+            using I0 = std::integral_constant<int, 0>;
+            static_for<4>([&](auto kc) { ld_row(I0{}, kc, I0{}, I0{}); });
+            ld_b(std::integral_constant<int, 0>{});
+            ld_b(std::integral_constant<int, 1>{});
+            static_for<9>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                static_for<6>([&](auto sc_) {
+                    constexpr int s_ = decltype(sc_)::value, ks = s_ / 3, kh = s_ % 3;
+                    constexpr int S = g * 2 + ks, q = S * 3 + kh;
+                    // prefetch: rows of super-step S+1 (two rows at kh = 0, one each at kh = 1, 2), B fragments of step q+2
+                    constexpr int S1 = S + 1;
+                    [[maybe_unused]] constexpr int nrows = kh == 0 ? 2 : 1;
+                    if constexpr (S1 < 18) {
+                        using SETC = std::integral_constant<int, S1 & 1>;
+                        using G1 = std::integral_constant<int, S1 / 2>;
+                        using K1 = std::integral_constant<int, S1 % 2>;
+                        if constexpr (kh == 0) { ld_row(SETC{}, std::integral_constant<int, 0>{}, G1{}, K1{}); ld_row(SETC{}, std::integral_constant<int, 1>{}, G1{}, K1{}); }
+                        else ld_row(SETC{}, std::integral_constant<int, kh + 1>{}, G1{}, K1{});
+                    }
+                    if constexpr (q + 2 < 54) ld_b(std::integral_constant<int, q + 2>{});
+#ifndef EXP_NO_MFMA
+                    acc0[0][0] = mfma16(rh[S & 1][kh], qh[q % 3], acc0[0][0]);
+                    acc1[0][0] = mfma16(rl[S & 1][kh], qh[q % 3], acc1[0][0]);
+                    acc1[0][0] = mfma16(rh[S & 1][kh], ql[q % 3], acc1[0][0]);
+                    acc0[1][0] = mfma16(rh[S & 1][kh + 1], qh[q % 3], acc0[1][0]);
+                    acc1[1][0] = mfma16(rl[S & 1][kh + 1], qh[q % 3], acc1[1][0]);
+                    acc1[1][0] = mfma16(rh[S & 1][kh + 1], ql[q % 3], acc1[1][0]);
+#endif
+                    if constexpr (DRAIN) drain_piece(std::integral_constant<int, q>{});
+                    {   // interleave as in the row-group loop: one LDS read and two VALU behind each MFMA
+                        constexpr int NRD_ = (S1 < 18 ? 2 * nrows : 0) + (q + 2 < 54 ? 2 : 0);
+#pragma unroll
+                        for (int m = 0; m < 6; ++m) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            if (m < NRD_) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                            if (m == 4) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+#ifndef EXP_NO_GROUP_BARRIER
+                if constexpr (g < 8) {
+                    STAMP(wave, sidx, lane);
+                    MSNET_LDS_BARRIER();                // g_g
+                    STAMP(wave, sidx, lane);
+                }
+#endif
+            });
+            if constexpr (DRAIN) {
+                if (pend_live) flag_overflow(a.oflag, pamax);
+                pamax = 0.f;
+                pend_live = false;
+#pragma unroll
+                for (int i = 0; i < MB; ++i) plw[i] = 0;
+            }
+        } else {
         const int gg0 = it * 9;
         // 3*KS steps per group (t = kw tap, ks = 16-channel K-step); fragments of step s+1 are read while step s multiplies.
         // The tile is stable across the group barriers, so the A fragments of a group's first step are read BEFORE the
@@ -1041,6 +1137,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         } else {
 #pragma unroll 1                                 // (expanding the nine groups here too was measured: Co=64 spills, stride 2 gains 1 %)
             for (int g = 0; g < 9; ++g) do_group(g, [](auto) {});
+        }
         }
         if (chunk == nchunks - 1) { pending = true; pn = n; pod0 = od0; poh0 = oh0; pow0 = ow0; pcg = cg; }
     }
