@@ -38,7 +38,8 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)", 
 FP16_MATRIX_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md "HBM3E peak BW" (spec); 6290 measured there with a float4 copy
 SPLIT_MFMAS_PER_PRODUCT = 3         # split-fp16: ah*wh, al*wh, ah*wl  
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+FACTS_FILE = os.path.join(ROOT, "profiles", "r03_profile_facts.json")     # tools/tools_profile_facts.py (rocprofv3 summaries)
 WORKLOADS = {
     # name: (padded H, W, maxdisp, description)
     "cfg2": (544, 960, 192, "MS-GCNet forward (MS volume build + 19-conv aggregator + soft-argmin), Scene-Flow "
@@ -84,6 +85,22 @@ def pmc_traffic(key, workload, batch):
         if rec.get("source_sha16") != _source_sha(*rec["sources"]):
             return None
         return rec["hbm_bytes"]
+    except Exception:
+        return None
+
+
+def profile_facts(workload, batch):
+    """Numbers of the committed rocprofv3 passes (profiles/r03_profile_facts.json: average kernel durations of the
+    --kernel-trace --stats run and the clock the chip held under the dominant kernel from the SQ/GRBM counter pass), returned
+    only when they were taken on this workload, this batch size and THIS kernel source -- so the live line and the tracked
+    profile cannot drift apart unnoticed.  Otherwise None."""
+    try:
+        rec = json.load(open(FACTS_FILE))
+        if rec.get("workload") != workload or rec.get("batch_per_gpu") != batch:
+            return None
+        if rec.get("source_sha16") != _source_sha(*rec["sources"]):
+            return None
+        return rec
     except Exception:
         return None
 
@@ -167,6 +184,23 @@ def measure_peaks(dev):
             "mfma_f16_16x16x32_TFLOPs": flops[0] / t_mfma16 / 1e9}
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without an external launcher: this process -- which has made NO GPU / HIP call yet and never
+    does -- starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process (it is never
+    replaced by another program), relays the child's output (rank 0's JSON line on stdout) and returns its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MSNET_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n))))
+    argv = [a for a in sys.argv[1:] if a != "--self-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,7 +217,13 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the aggregator forward from a captured HIP graph (module.use_graph); its launches then carry no "
                          "HIP events, so the roofline of the dominant kernel is not measured in such a run -- diagnostic, not the default")
+    ap.add_argument("--self-launch", action="store_true",
+                    help="start the ranks as a child `python -m torch.distributed.run` even for --gpus 1 (what --gpus N>1 does by "
+                         "itself when no launcher set RANK)")
     args = ap.parse_args()
+
+    if (args.gpus > 1 or args.self_launch) and "RANK" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))
 
     import msnets_amd
     from msnets_amd import _lib, cbmv_generator, dist as msdist, hipops, synthetic
@@ -312,7 +352,13 @@ def main():
                        "parallelism": "dp%d (rank-sharded pairs, RCCL all-gather of disparity maps)" % world,
                        "includes_volume_build": not args.no_volume, "hip_graph": bool(args.graph),
                        "collective": ("rccl all_gather_into_tensor" if torch.distributed.is_available() and
-                                      torch.distributed.is_initialized() else "none (single process)")},
+                                      torch.distributed.is_initialized() else "none (single process)"),
+                       "world_size": (torch.distributed.get_world_size() if torch.distributed.is_available() and
+                                      torch.distributed.is_initialized() else 1),
+                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if torch.distributed.is_available()
+                                        and torch.distributed.is_initialized() else None),
+                       "launcher": ("bench.py self-launch (child torch.distributed.run)" if os.environ.get("MSNET_BENCH_SELF_LAUNCHED")
+                                    else "torch.distributed.run" if "RANK" in os.environ else "single process")},
             "step_ms": {"median": pct(50), "p10": pct(10), "p90": pct(90), "source": "HIP events between steps, rank 0"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
                          "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -321,6 +367,27 @@ def main():
                          "all_conv_tflops": (conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0) if all_timed else None,
                          "traffic": pmc_traffic(dom_family, args.workload, B)},
         }
+        facts = profile_facts(args.workload, B)
+        if facts:
+            # the tracked rocprofv3 --kernel-trace --stats run of this very source: average duration of the dominant kernel
+            ns = facts.get("kernel_avg_ns", {}).get(dom_family)
+            if ns and dom["calls"]:
+                fl = dom["flops"] / dom["calls"]
+                line["roofline"]["avg_launch_ms_rocprof"] = ns * 1e-6
+                line["roofline"]["frac_rocprof"] = fl / (ns * 1e-9) / 1e12 / peak
+            line["roofline"]["sustained_clock_ghz"] = facts.get("sustained_clock_ghz", {}).get(dom_family)
+            line["roofline"]["profile_facts"] = os.path.relpath(FACTS_FILE, ROOT)
+        else:
+            line["roofline"].update(avg_launch_ms_rocprof=None, frac_rocprof=None, sustained_clock_ghz=None,
+                                    profile_facts="none for this kernel source (profiles/ holds an older build's)")
+        if args.workload != "cfg3" and args.precision != "fp32":
+            # whole-step MFMA roofline without per-launch events: the 19 convs' algorithmic FLOPs per map / the step time
+            # (volume build, layout conversion, tail and all gaps included) vs the same peak as `roofline`
+            step_tf = gcnet_flops(H, W, D) * n_total / world / (1e-3 * 1e3 * dt / args.steps) / 1e12
+            line["roofline_step"] = {"bound": "mfma", "achieved": step_tf, "peak": peak, "unit": "TFLOP/s", "frac": step_tf / peak,
+                                     "flops_per_map": gcnet_flops(H, W, D),
+                                     "note": "per GPU: algorithmic conv FLOPs of the maps one rank processes per step / wall "
+                                             "time per step; " + peak_note}
         volk = {k: v for k, v in prof.items() if k.startswith(VOLUME_FAMILIES)}
         if volk and not args.no_volume:
             vms = sum(v["ms"] for v in volk.values())
@@ -350,6 +417,9 @@ def main():
                 att = pk["mfma_f16_TFLOPs"] / mfmas
                 line["roofline"]["peak_attainable"] = att
                 line["roofline"]["frac_attainable"] = achieved / att if att > 0 else None
+                if "roofline_step" in line:
+                    line["roofline_step"]["peak_attainable"] = att
+                    line["roofline_step"]["frac_attainable"] = line["roofline_step"]["achieved"] / att if att > 0 else None
             if "roofline_volume" in line:
                 line["roofline_volume"]["peak_attainable"] = pk["hbm_copy_GBs"]
                 line["roofline_volume"]["frac_attainable"] = line["roofline_volume"]["achieved"] / pk["hbm_copy_GBs"]

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void ncs_to_nsc_kernel(const float* __restrict
     }
     for (; c < C; ++c)
         if (tid < cnt) { const float v = sp[(size_t)c * S + tid]; amax = fmaxf(amax, fabsf(v)); tile[c * LS + tid] = v; }
-    if (oflag && !(amax < 65504.f)) atomicOr(oflag, 1u);
+    if (oflag && !(amax < 65504.f)) atomicOr(oflag, 2u);    // bit 1: the module INPUT left the range (a per-call condition, hipops.py)
     __syncthreads();
     float* dp = dst + ((size_t)n * S + s0) * C;
     const int total = cnt * C;

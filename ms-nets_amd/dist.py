@@ -15,7 +15,7 @@ import torch.distributed as dist
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
     Returns (rank, world_size, local_rank).  A plain single-process run (no RANK) returns (0, 1, 0)."""
-    if "RANK" not in os.environ or int(os.environ.get("WORLD_SIZE", "1")) == 1 and "RANK" not in os.environ:
+    if "RANK" not in os.environ:
         return 0, 1, 0
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank))

@@ -29,13 +29,13 @@ def save_pfm(fname, image, scale=1):
     encodes the byte order (negative = little endian)."""
     image = np.asarray(image)
     if image.dtype.name != "float32":
-        raise Exception("Image dtype must be float32.")
+        raise Exception("save_pfm writes float32 data only (got dtype %s)" % image.dtype.name)
     if image.ndim == 3 and image.shape[2] == 3:
         color = True
     elif image.ndim == 2 or (image.ndim == 3 and image.shape[2] == 1):
         color = False
     else:
-        raise Exception("Image must have H x W x 3, H x W x 1 or H x W dimensions.")
+        raise Exception("save_pfm takes an [H,W], [H,W,1] or [H,W,3] array (got shape %s)" % (image.shape,))
     endian = image.dtype.byteorder
     if endian == "<" or (endian == "=" and sys.byteorder == "little"):
         scale = -scale
@@ -65,10 +65,21 @@ def read_pfm(fname):
 
 def get_epe_rate(disp, prediction, max_disp=192, threshold=3.0):
     """End-point error and bad-`threshold` rate over the pixels with 0.001 <= gt <= max_disp (main_msnet.py:708-713).
-    NumPy arrays are evaluated on the host as in the reference; two GPU tensors are reduced on the device
-    (msnet_epe_badx: one HBM pass, 24 bytes back) so the disparity map never has to be copied to the host for the metric."""
-    if hasattr(disp, "is_cuda") or hasattr(prediction, "is_cuda"):
-        return get_epe_rate_gpu(disp, prediction, max_disp, threshold)
+    NumPy arrays / CPU tensors are evaluated on the host as in the reference; when either operand is a GPU tensor the other is
+    uploaded and both are reduced on the device (msnet_epe_badx: one HBM pass, 24 bytes back), so a GPU disparity map never
+    has to be copied to the host for the metric."""
+    d_gpu, p_gpu = bool(getattr(disp, "is_cuda", False)), bool(getattr(prediction, "is_cuda", False))
+    if d_gpu or p_gpu:
+        # the usual driver case is a GPU prediction with a ground truth read from a PFM file (NumPy / CPU tensor): the host
+        # side is uploaded to the prediction's device; two host-side operands never touch the GPU
+        import torch
+        dev = (prediction if p_gpu else disp).device
+        up = lambda a: a if bool(getattr(a, "is_cuda", False)) else torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32).to(dev)   # noqa: E731
+        return get_epe_rate_gpu(up(disp), up(prediction), max_disp, threshold)
+    if hasattr(disp, "detach"):
+        disp = disp.detach().numpy()
+    if hasattr(prediction, "detach"):
+        prediction = prediction.detach().numpy()
     mask = np.logical_and(disp >= 0.001, disp <= max_disp)
     err = np.abs(prediction[mask] - disp[mask])
     return np.mean(err), np.sum(err > threshold) / np.sum(mask)

@@ -210,8 +210,10 @@ def trilinear_softargmin(cost, out_dhw):
 
 class RangeGuard:
     """fp16-range guard for one forward on the split-fp16 kernels: registers a device word with the library
-    (msnet_set_overflow_flag); every conv epilogue and the input layout conversion raise it when they see a magnitude the
-    split (hi = fp16(x)) cannot represent.  `tripped()` reads it back (one 4-byte device-to-host copy = one sync per forward)."""
+    (msnet_set_overflow_flag); every conv epilogue ORs bit 0 into it when it stores a magnitude the split (hi = fp16(x)) cannot
+    represent, the layout conversion of the module INPUT ORs bit 1.  `word()` reads it back (one 4-byte device-to-host copy
+    = one sync per forward)."""
+    ACTIVATION, INPUT = 1, 2
 
     def __init__(self, device):
         self.flag = torch.zeros(1, dtype=torch.int32, device=device)
@@ -225,8 +227,11 @@ class RangeGuard:
         _lib.load().msnet_set_overflow_flag(None)
         return False
 
+    def word(self):
+        return int(self.flag.item())
+
     def tripped(self):
-        return bool(int(self.flag.item()))
+        return bool(self.word())
 
 
 class exact_tails:
@@ -240,14 +245,39 @@ class exact_tails:
         return False
 
 
+def _current_precision(module):
+    """The module's sticky fp32 fallback belongs to the parameter state it was raised for: load_state_dict / .to() / any
+    tracked in-place edit (state_key) lifts it."""
+    if module._forced_precision is not None and getattr(module, "_forced_key", None) != state_key(module):
+        module._forced_precision = None
+    return module._forced_precision or _default_precision
+
+
+def _range_fallback(module, run, word):
+    """A forward on the split-fp16 kernels raised the range flag: repeat it on the exact fp32 kernels.  Raised by an
+    ACTIVATION (a property of the weights -- it would recur): the module stays on fp32 until its parameters change or
+    invalidate_plans().  Raised only by the module INPUT (one out-of-range / NaN / inf voxel in this sample): this call only,
+    so one bad sample in a serving loop does not move the module onto the slower path for good."""
+    sticky = bool(word & RangeGuard.ACTIVATION)
+    warnings.warn("msnet: %s left the fp16 range (|x| >= 65504) of the split-fp16 conv kernels; this forward was repeated on the "
+                  "exact fp32 MFMA kernels%s" % ("an activation" if sticky else "the module input",
+                                                 ", which this module now keeps using" if sticky else " (this call only)"),
+                  RuntimeWarning)
+    if sticky:
+        module._forced_precision = "fp32"
+        module._forced_key = state_key(module)
+    with exact_tails():
+        return run("fp32")
+
+
 def guarded_forward(module, run, graph_key=None):
     """Shared by the two aggregators.  run(precision) -> output.  On the split-fp16 path the forward runs under a
     RangeGuard; if an activation (or the input) left the fp16 range the result is discarded, a warning is issued and the
-    forward is repeated on the exact fp32-input MFMA kernels with fp32 tails -- and the module stays there (sticky until
-    invalidate_plans()), so a checkpoint with large activations costs the sync and the double forward once.
+    forward is repeated on the exact fp32-input MFMA kernels with fp32 tails (_range_fallback: sticky for activations, per
+    call for the input).
     graph_key (input address, shapes): with module.use_graph set, the forward is captured once per key as a HIP graph and
     replayed afterwards (_graphed_forward)."""
-    precision = module._forced_precision or _default_precision
+    precision = _current_precision(module)
     run_ = run
 
     def run(prec):                      # activations come from the module's arena (not when taps are handed out)
@@ -265,12 +295,9 @@ def guarded_forward(module, run, graph_key=None):
         guard = module._guard = RangeGuard(next(module.parameters()).device)
     with guard:
         out = run(precision)
-    if guard.tripped():
-        warnings.warn("msnet: an activation left the fp16 range (|x| >= 65504) of the split-fp16 conv kernels; this forward "
-                      "was repeated on the exact fp32 MFMA kernels, which this module now keeps using", RuntimeWarning)
-        module._forced_precision = "fp32"
-        with exact_tails():
-            out = run("fp32")
+    word = guard.word()
+    if word:
+        out = _range_fallback(module, run, word)
     return out
 
 
@@ -281,11 +308,14 @@ def _graphed_forward(module, run, graph_key):
     """module.use_graph = True: the ~45 launches of a forward (and their host work: ctypes calls, shape checks, buffer
     look-ups) become one hipGraphLaunch.  A graph is tied to the input's ADDRESS and shape, the precision and the parameter
     state (state_key: the check the eager path makes too), so it pays in loops that reuse their input buffer -- a serving
-    loop, bench.py --graph; up to MAX_GRAPHS_PER_MODULE keys are kept.  The first call per key runs eagerly (plans, arena,
-    range fallback), the second captures.  The range guard stays on: its flag is cleared inside the graph and read after the
-    replay; a trip drops the graphs and repeats the forward eagerly on fp32.  Returns a copy of the graph's output buffer."""
+    loop, bench.py --graph; up to MAX_GRAPHS_PER_MODULE keys are kept.  The first call per key runs eagerly (plans, range
+    fallback), the second captures.  A graph bakes in the ADDRESSES of its activation buffers, so every graph owns its
+    Arena (filled by one eager pass right before the capture, so the capture itself allocates nothing): a later forward of
+    another shape re-sizes the module's arena, never a captured graph's buffers.  The range guard stays on: its flag is
+    cleared inside the graph and read after the replay; a trip drops the graphs and repeats the forward eagerly on fp32.
+    Returns a copy of the graph's output buffer."""
     graphs = module.__dict__.setdefault("_graphs", {})
-    precision = module._forced_precision or _default_precision
+    precision = _current_precision(module)
     key = tuple(graph_key) + (precision, state_key(module))
     g = graphs.get(key)
     if g is None:
@@ -294,7 +324,7 @@ def _graphed_forward(module, run, graph_key):
             out = guarded_forward(module, run)          # eager: builds plans and arena, settles the precision
         finally:
             module.use_graph = True
-        if (module._forced_precision or _default_precision) == precision:      # (else: the range guard moved the module to fp32)
+        if _current_precision(module) == precision:     # (else: the range guard moved the module to fp32)
             if len(graphs) >= MAX_GRAPHS_PER_MODULE:
                 graphs.pop(next(iter(graphs)))
             graphs[key] = {"graph": None}               # captured on the next call with this key
@@ -302,32 +332,43 @@ def _graphed_forward(module, run, graph_key):
     if g["graph"] is None:
         dev = next(module.parameters()).device
         guard = RangeGuard(dev) if precision == "split-fp16" and module.range_check else None
+        arena = Arena()
+
+        def body():
+            with use_arena(arena):
+                if precision != "split-fp16":
+                    with exact_tails():
+                        return run(precision)
+                return run(precision)
+        body()                                          # eager pass through the graph's own arena: all its allocations
         torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
             if guard is not None:
                 guard.__enter__()
             try:
-                with use_arena(module._arena):
-                    if precision != "split-fp16":
-                        with exact_tails():
-                            out = run(precision)
-                    else:
-                        out = run(precision)
+                out = body()
             finally:
                 if guard is not None:
                     guard.__exit__()
-        g.update(graph=graph, out=out, guard=guard)
+        g.update(graph=graph, out=out, guard=guard, arena=arena)
     g["graph"].replay()
-    if g["guard"] is not None and g["guard"].tripped():
-        graphs.clear()
+    word = g["guard"].word() if g["guard"] is not None else 0
+    if word:
+        if word & RangeGuard.ACTIVATION:
+            graphs.clear()
         module.use_graph = False
         try:
-            return guarded_forward(module, run)         # warns, repeats on fp32, makes that sticky
+            return _range_fallback(module, lambda prec: _with_arena(module, run, prec), word)
         finally:
             module.use_graph = True
     out = g["out"]
     return tuple(t.clone() for t in out) if isinstance(out, tuple) else out.clone()
+
+
+def _with_arena(module, run, prec):
+    with use_arena(module._arena if module._use_arena else None):
+        return run(prec)
 
 
 class ConvBNPlan:
@@ -367,9 +408,17 @@ class ConvBNPlan:
                               "this layer runs on the fp32 MFMA kernel" % wmax, RuntimeWarning)
                 self.f16s = False
             else:
-                w = wf
-                if self.scale is not None:
-                    self.scale = None
+                # Per-output-channel power-of-two pre-scale: channel c's folded weights are multiplied by 2^k_c so that their
+                # largest magnitude lies in [2^8, 2^9) and the epilogue multiplies the accumulator by 2^-k_c (`scale`, exact).
+                # hi + lo*2^-11 carries 22 bits only while |w| >= 2^-13 (below that the fp16 halves run out of exponent and
+                # the error floor is 2^-35 absolute), so a channel whose folded weights are all tiny (small gamma, large
+                # running_var) would otherwise lose precision.  Bit-identical to the unscaled form whenever no half underflows.
+                red = (0, 2, 3, 4) if transposed else (1, 2, 3, 4)
+                cmax = wf.abs().amax(dim=red)
+                k = torch.where(cmax > 0, 8 - torch.floor(torch.log2(cmax.clamp_min(1e-38))), torch.zeros_like(cmax))
+                k = k.clamp(-100, 100)
+                w = wf * torch.exp2(k).view(shape)
+                self.scale = torch.exp2(-k).contiguous()
         self.wpk = pack_conv_weight(w, transposed, f16s=self.f16s, stride=stride)
 
 

@@ -1,0 +1,149 @@
+"""Generates tests/golden/fullsize_<case>.npz: the REFERENCE aggregators (/root/reference/src/models/, imported
+unmodified, same harness-side shims as make_aggregator_golden.py) run on CPU at the FULL benchmark shapes of
+BASELINE.json configs #2 / #5 (MS-GCNet) and #3 (PSMNet aggregator), with random-init and with `peaky`
+(trained-network-like softmax) weights -- recipes.FULL_CASES.
+
+Runs only in the build container (needs /root/reference, ~10 GB of RAM, a few minutes); what it writes is data:
+the reference's full disparity map, strided samples of its activations / logits, the sha256 of the seeded
+state_dict, and softmax statistics of the case (printed and stored, so a reader can see how peaky it is).
+
+    python tests/golden/make_fullsize_golden.py [case ...]
+"""
+import contextlib
+import io
+import os
+import sys
+import time
+
+os.environ["PYTHONDONTWRITEBYTECODE"] = "1"
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+sys.path.insert(0, "/root/reference")
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+import recipes
+from oracle import aggregators as oracle
+
+torch.Tensor.cuda = lambda self, *a, **k: self          # D1
+import src.models.gcnet_3dcnn as ref_gc                # noqa: E402
+import src.models.psmnet_3dcnn as ref_psm              # noqa: E402
+
+import msnets_amd                                      # noqa: E402,F401
+from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre as OurGC      # noqa: E402
+from msnets_amd.psmnet_3dcnn import PSMNet_CostVolumeAggre as OurPSM   # noqa: E402
+
+GC_TAPS = ["conv3dbn_1", "conv3dbn_2", "block_3d_1", "block_3d_2", "block_3d_3", "block_3d_4", "deconv5"]
+NS = recipes.FULL_MAX_SAMPLES
+
+
+def case_input(case):
+    if case.get("ms_volume"):
+        from oracle import ms_volume as O
+        from msnets_amd import synthetic
+        n, c, d, h, w = case["in_shape"]
+        left, right, _ = synthetic.stereo_pair(h, w, d, seed=case["seed"])
+        return torch.from_numpy(O.build_ms_volume(left, right, d)).unsqueeze(0)
+    return recipes.full_input(case)
+
+
+def softmax_stats(logits):
+    """logits [1,D,H,W] fp32 -> dict of how peaky the case is (fp64 softmax)."""
+    out = {}
+    pmax, kap = [], []
+    for h0 in range(0, logits.shape[2], 32):                     # in slabs: the fp64 softmax of the whole map is 800 MB
+        l = logits[:, :, h0:h0 + 32].double()
+        p = F.softmax(l, 1)
+        d = torch.arange(l.shape[1], dtype=torch.float64).view(1, -1, 1, 1)
+        disp = (p * d).sum(1, keepdim=True)
+        kap.append((p * (d - disp).abs()).sum(1).flatten())
+        pmax.append(p.max(1)[0].flatten())
+    pmax, kap = torch.cat(pmax), torch.cat(kap)
+    out["logit_absmax"] = float(logits.abs().max())
+    out["pmax_median"] = float(pmax.median())
+    out["pmax_p10"] = float(pmax.kthvalue(max(1, pmax.numel() // 10))[0])
+    out["kappa_median"] = float(kap.median())
+    out["kappa_max"] = float(kap.max())
+    return out
+
+
+def run_case(name, case):
+    t0 = time.time()
+    torch.set_num_threads(8)
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = recipes.build_case(case, ref_gc.GCNet_CostVolumeAggre, ref_psm.PSMNet_CostVolumeAggre)
+        ours = recipes.build_case(case, OurGC, OurPSM)
+    sd = {k: v.clone() for k, v in ref.state_dict().items()}
+    sha = recipes.state_sha256(sd)
+    assert sha == recipes.state_sha256(ours.state_dict()), "our seeded init differs from the reference's"
+    del ours
+    x = case_input(case)
+    assert tuple(x.shape) == tuple(case["in_shape"]), x.shape
+    H, W = recipes.out_hw(case)
+    samples, hooks, keep = {}, [], {}
+
+    def hook(t, relu):
+        def f(m, i, o):
+            s, stride = recipes.sample(o, NS)
+            samples[t] = (np.maximum(s, 0) if relu else s, stride)
+            if t == "deconv5":
+                keep["logits"] = o.detach().squeeze(1).clone()
+            if t.startswith("classif"):
+                keep[t] = o.detach().clone()
+        return f
+    if case["model"] == "gcnet":
+        for t in GC_TAPS:
+            # conv3dbn_*: the reference applies its (in-place) ReLU outside the Sequential, so the sample gets it here
+            hooks.append(getattr(ref, t).register_forward_hook(hook(t, t.startswith("conv3dbn"))))
+    else:
+        ref_psm.left = torch.empty(1, 3, H, W)          # D2
+        for t in ("classif1", "classif2", "classif3"):
+            hooks.append(getattr(ref, t).register_forward_hook(hook(t, False)))
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        disp = ref(x.clone())
+    for h in hooks:
+        h.remove()
+    out = {"disp": disp.numpy().astype(np.float32), "state_sha256": np.array(sha)}
+    if case["model"] == "gcnet":
+        logits = keep.pop("logits")
+    else:
+        cost2 = keep["classif2"] + keep["classif1"]                 # psmnet_3dcnn.py:140-147, same order => same bits
+        cost3 = keep["classif3"] + cost2
+        s, stride = recipes.sample(cost3, NS)
+        samples = {"cost3": (s, stride)}
+        logits = F.interpolate(cost3, [case["maxdisp"], H, W], mode="trilinear", align_corners=True).squeeze(1)
+        assert torch.equal(oracle.soft_argmin(logits), disp)
+    stats = softmax_stats(logits)
+    del logits
+    # the oracle restatement must reproduce the reference at this size too (disparity only: no second 8 GB of taps)
+    with torch.no_grad():
+        if case["model"] == "gcnet":
+            d_or = oracle.gcnet_forward(sd, x, case["maxdisp"])
+        else:
+            d_or = oracle.psmnet_forward(sd, x, case["maxdisp"], (H, W))
+    err = float((d_or - disp).abs().max())
+    assert err < 1e-4, (name, err)
+    out["oracle_max_abs_err"] = np.float32(err)
+    for t, (s, stride) in samples.items():
+        out["tap_" + t] = s
+        out["tapstride_" + t] = np.int64(stride)
+    for k, v in stats.items():
+        out["stat_" + k] = np.float64(v)
+    path = os.path.join(HERE, "fullsize_%s.npz" % name)
+    np.savez_compressed(path, **out)
+    print("%-20s disp %s range [%.2f, %.2f]  oracle-vs-reference %.1e  max|logit| %.1f  pmax median %.3f p10 %.3f  "
+          "kappa median %.2f max %.1f  -> %s (%.2f MB, %.0f s)"
+          % (name, tuple(disp.shape), disp.min(), disp.max(), err, stats["logit_absmax"], stats["pmax_median"],
+             stats["pmax_p10"], stats["kappa_median"], stats["kappa_max"], os.path.basename(path),
+             os.path.getsize(path) / 1e6, time.time() - t0), flush=True)
+
+
+if __name__ == "__main__":
+    names = sys.argv[1:] or list(recipes.FULL_CASES)
+    for name in names:
+        run_case(name, recipes.FULL_CASES[name])

@@ -23,6 +23,21 @@ AGG_CASES = {
 }
 MAX_SAMPLES = 4096
 
+# Full-size cases (BASELINE.json configs #2, #5, #3), produced by tests/golden/make_fullsize_golden.py from the REFERENCE
+# itself: random-init and `peaky` (trained-network-like softmax) weights; `ms_volume`: the input is the MS volume of the
+# seeded synthetic stereo pair (oracle/ms_volume.py -- the real feature statistics) instead of torch.rand.
+FULL_CASES = {
+    "gcnet_cfg2": dict(model="gcnet", seed=31, maxdisp=192, in_shape=(1, 8, 96, 272, 480)),
+    "gcnet_cfg2_peaky": dict(model="gcnet", seed=32, maxdisp=192, in_shape=(1, 8, 96, 272, 480), peaky=25.0),
+    "gcnet_cfg2_ms_peaky": dict(model="gcnet", seed=33, maxdisp=192, in_shape=(1, 8, 96, 272, 480), peaky=25.0,
+                                ms_volume=True),
+    "gcnet_cfg5": dict(model="gcnet", seed=34, maxdisp=192, in_shape=(1, 8, 96, 192, 624)),
+    "gcnet_cfg5_peaky": dict(model="gcnet", seed=35, maxdisp=192, in_shape=(1, 8, 96, 192, 624), peaky=25.0),
+    "psmnet_cfg3": dict(model="psmnet", seed=36, maxdisp=192, in_shape=(1, 64, 48, 136, 240)),
+    "psmnet_cfg3_peaky": dict(model="psmnet", seed=37, maxdisp=192, in_shape=(1, 64, 48, 136, 240), peaky=2.0),
+}
+FULL_MAX_SAMPLES = 65536
+
 
 def randomize_bn(model, seed):
     g = torch.Generator().manual_seed(10_000 + seed)
@@ -43,8 +58,11 @@ def make_input(shape, seed):
 def apply_options(model, case):
     """Post-construction tweaks of a case; `peaky` scales deconv5 so the softmax is sharply peaked
     (trained-network-like), the regime where reduced-precision convs fail by pixels."""
-    if case.get("peaky"):
+    if case.get("peaky") and case["model"] == "gcnet":
         model.deconv5.weight.data.mul_(case["peaky"])
+    elif case.get("peaky"):                 # PSMNet: the three classification heads' last conv (psmnet_3dcnn.py:110-122)
+        for head in (model.classif1, model.classif2, model.classif3):
+            head[2].weight.data.mul_(case["peaky"])
 
 
 def state_sha256(sd):
@@ -56,10 +74,10 @@ def state_sha256(sd):
     return h.hexdigest()
 
 
-def sample(t):
-    """Deterministic strided sample of a tensor (<= MAX_SAMPLES values) + its flat stride."""
+def sample(t, max_samples=MAX_SAMPLES):
+    """Deterministic strided sample of a tensor (<= max_samples values) + its flat stride."""
     flat = t.detach().reshape(-1)
-    stride = max(1, flat.numel() // MAX_SAMPLES)
+    stride = max(1, flat.numel() // max_samples)
     return flat[::stride].cpu().numpy().astype(np.float32), stride
 
 
@@ -81,3 +99,9 @@ def out_hw(case):
         return 4 * h, 4 * w
     s = 4 if case.get("quarter") else 2
     return s * h, s * w
+
+
+def full_input(case):
+    """Input volume of a FULL_CASES entry: torch.rand, or (ms_volume) the oracle's MS volume of the seeded synthetic pair --
+    the caller passes it in because this file must not import oracle/ (the tests do)."""
+    return make_input(case["in_shape"], case["seed"])

@@ -607,6 +607,70 @@ def test_fp16_range_guard_reruns_on_fp32(gpu):
     assert ok._forced_precision is None
 
 
+@pytest.mark.parametrize("ci,co,stride,transposed", [(32, 32, 1, False), (64, 64, 1, False), (8, 32, 1, False), (32, 64, 2, False),
+                                                      (64, 32, 1, True), (128, 128, 1, False)])
+@pytest.mark.parametrize("xs,ws", [(1.0e-5, 1.0), (1.0, 1.0e-5), (1.0e-5, 1.0e-5), (3.0e-4, 1.0e-3)])
+def test_split_fp16_small_magnitudes(gpu, ci, co, stride, transposed, xs, ws):
+    """Underflow twin of the range guard, per layer: activations and / or BN-folded weights of magnitude ~1e-5, i.e. below
+    2^-14 where `hi = fp16(x)` is an fp16 SUBNORMAL.  ConvBNPlan's per-channel power-of-two pre-scale brings every folded
+    weight back into the normal range (exact); small activations rely on the fp16 MFMA keeping subnormal inputs (it does on
+    gfx950 -- this test is what establishes it) and carry an absolute error floor of 2^-35 per operand (lo's last subnormal
+    bit), i.e. ~3e-6 relative at 1e-5.  Gate: 5e-6 of the layer's output magnitude, as for O(1) data."""
+    from msnets_amd import hipops
+    g = torch.Generator().manual_seed(ci * 13 + co + stride)
+    dims = (1, 4, 9, 40) if ci < 128 else (1, 3, 5, 9)
+    n, d, h, w = dims
+    x = torch.randn((n, ci, d, h, w), generator=g) * 3 * xs
+    if transposed:
+        conv = torch.nn.ConvTranspose3d(ci, co, 3, stride=2, padding=1, output_padding=1, bias=False)
+    else:
+        conv = torch.nn.Conv3d(ci, co, 3, stride=stride, padding=1, bias=False)
+    bn = torch.nn.BatchNorm3d(co)
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(conv.weight.shape, generator=g) * (2.0 / (27 * ci)) ** 0.5)
+        bn.weight.copy_((torch.rand(co, generator=g) + 0.5) * ws)
+        bn.bias.copy_(torch.randn(co, generator=g) * 0.1 * xs * ws)
+        bn.running_mean.copy_(torch.randn(co, generator=g) * 0.1 * xs)
+        bn.running_var.copy_(torch.rand(co, generator=g) * 0.5 + 0.75)
+    conv, bn = conv.eval(), bn.eval()
+    with torch.no_grad():
+        ref = F.relu(bn.double()(conv.double()(x.double())))
+    conv, bn = conv.float().cuda(), bn.float().cuda()
+    plan = hipops.ConvBNPlan(conv, bn, transposed=transposed, precision="split-fp16")
+    assert plan.f16s
+    if transposed:
+        y = hipops.deconv3d_k3s2(_cl(x), plan.wpk, plan.scale, plan.shift, co, relu=True, f16s=True)
+    else:
+        y = hipops.conv3d_k3(_cl(x), plan.wpk, plan.scale, plan.shift, co, stride=stride, relu=True, f16s=True)
+    err = _rel(_nc(y).double(), ref)
+    print("split-fp16 small magnitudes %d->%d s%d%s x*%.0e w*%.0e: rel err %.2e (max|ref| %.2e)"
+          % (ci, co, stride, " T" if transposed else "", xs, ws, err, float(ref.abs().max())))
+    assert float(ref.abs().max()) > 0
+    assert err < 5e-6
+
+
+def test_small_activations_end_to_end(gpu):
+    """Underflow twin of test_fp16_range_guard_reruns_on_fp32 at the module level: conv3dbn_2's output (= the res_l20 skip
+    connection) and its folded weights are scaled to ~1e-5, compensated downstream.  The split-fp16 forward must still match
+    the oracle to 1e-3 -- with no fallback (no warning, no fp32 re-run)."""
+    import warnings
+    m = _big_activation_model(1.0e-5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.rand((1, 8, 16, 16, 32), generator=torch.Generator().manual_seed(12))
+    with torch.no_grad():
+        taps_or = {}
+        ref = oracle.gcnet_forward(sd, x, 32, taps=taps_or)
+    assert float(taps_or["conv3dbn_2"].abs().max()) < 2e-4          # the activations really are in the subnormal-hi range
+    m = m.cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = m(x.cuda()).cpu()
+    assert m._forced_precision is None
+    err = float((got - ref).abs().max())
+    print("small activations end to end: max|disp - oracle| = %.3e" % err)
+    assert err <= DISP_TOL
+
+
 def test_fp16_range_of_folded_weights(gpu):
     """A BN scale that pushes a folded weight beyond 65504 (tiny running_var / huge gamma): that layer is planned on the fp32
     MFMA kernel (with a warning) instead of producing an infinite `hi` half."""
@@ -694,8 +758,10 @@ def test_graphed_forward_equals_eager(gpu):
 
 
 def test_graphed_forward_range_guard(gpu):
-    """The fp16-range guard stays armed under graph replay: an out-of-range input trips it after the replay, the graphs are
-    dropped and the forward is repeated on the fp32 kernels."""
+    """The fp16-range guard stays armed under graph replay: an out-of-range INPUT trips it after the replay and that forward is
+    repeated on the fp32 kernels -- for this call only (the graphs and the split-fp16 path stay); an out-of-range ACTIVATION
+    drops the graphs and keeps the module on fp32."""
+    import warnings
     from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre
     torch.manual_seed(4)
     model = GCNet_CostVolumeAggre(32).eval().cuda()
@@ -704,8 +770,78 @@ def test_graphed_forward_range_guard(gpu):
     a = model(x); b = model(x); c = model(x)
     assert torch.equal(a, b) and torch.equal(b, c)
     x[0, 0, 0, 0, 0] = 1e5
-    with pytest.warns(RuntimeWarning, match="fp16 range"):
+    with pytest.warns(RuntimeWarning, match="module input"):
         y = model(x)
-    assert bool(torch.isfinite(y).all()) and model._forced_precision == "fp32" and not model._graphs
+    assert bool(torch.isfinite(y).all()) and model._forced_precision is None and len(model._graphs) == 1
     model.use_graph = False
-    assert torch.allclose(y, model(x), atol=0, rtol=0)
+    with pytest.warns(RuntimeWarning, match="module input"):
+        assert torch.equal(y, model(x))                            # eager: the same per-call fallback, the same bits
+    model.use_graph = True
+    x[0, 0, 0, 0, 0] = 0.5
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                             # the sample after the bad one: split-fp16 graph replay again
+        z = model(x)
+    model.use_graph = False
+    assert torch.equal(z, model(x))
+    # activation trip under replay: the same buffer now holds values just inside the fp16 range, so the INPUT passes but the
+    # first conv's outputs do not: sticky, graphs dropped
+    model.use_graph = True
+    x.mul_(6.0e4)
+    with pytest.warns(RuntimeWarning, match="an activation"):
+        w = model(x)
+    assert bool(torch.isfinite(w).all()) and model._forced_precision == "fp32" and not model._graphs
+    w1 = model(x); w2 = model(x); w3 = model(x)                    # fp32 key: eager, capture, replay
+    assert torch.equal(w1, w) and torch.equal(w2, w) and torch.equal(w3, w)
+
+
+def test_graph_survives_arena_resize(gpu):
+    """A captured graph bakes in the addresses of its activation buffers.  Shape A (captured), then shape B (re-sizes the
+    module's arena and allocates where A's buffers might have been freed), then shape A again: the replay must still return
+    shape A's result -- every graph owns its arena (replay into freed memory)."""
+    from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre
+    torch.manual_seed(6)
+    model = GCNet_CostVolumeAggre(32).eval().cuda()
+    xa = torch.rand((1, 8, 16, 32, 48), device="cuda")
+    xb = torch.rand((1, 8, 16, 48, 80), device="cuda")
+    ref_a, ref_b = model(xa).clone(), model(xb).clone()
+    model.use_graph = True
+    for _ in range(3):
+        assert torch.equal(model(xa), ref_a)                       # eager, capture, replay
+    for _ in range(3):
+        assert torch.equal(model(xb), ref_b)                       # shape B: module arena re-sized, own graph
+    junk = [torch.full((1, 16, 32, 48, 32), float(k), device="cuda") for k in range(8)]   # take whatever memory was released
+    assert torch.equal(model(xa), ref_a)                           # replay of graph A
+    assert torch.equal(model(xb), ref_b)
+    model.use_graph = False
+    assert torch.equal(model(xa), ref_a) and torch.equal(model(xb), ref_b)   # eager passes in between do not disturb the graphs
+    model.use_graph = True
+    assert torch.equal(model(xa), ref_a) and torch.equal(model(xb), ref_b)
+    del junk
+
+
+def test_range_fallback_scope(gpu):
+    """the fp32 fallback is sticky only when an ACTIVATION raised the flag, and even then only for the parameter
+    state it was raised for.  One bad input sample costs one repeated forward, not the module's speed."""
+    import warnings
+    G, _ = _our_classes()
+    torch.manual_seed(7)
+    m = G(32).eval().cuda()
+    x = torch.rand((1, 8, 16, 16, 32), device="cuda")
+    good = m(x).clone()
+    bad = x.clone()
+    bad[0, 3, 2, 5, 7] = float("inf")
+    with pytest.warns(RuntimeWarning, match="module input"):
+        m(bad)
+    assert m._forced_precision is None
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert torch.equal(m(x), good)                             # the next sample is back on split-fp16, no warning
+    big = _big_activation_model(3.0e5).cuda()
+    with pytest.warns(RuntimeWarning, match="an activation"):
+        big(x)
+    assert big._forced_precision == "fp32"
+    big.load_state_dict(m.state_dict())                            # new parameters: the fallback is lifted
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert torch.equal(big(x), good)
+    assert big._forced_precision is None

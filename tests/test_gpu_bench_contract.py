@@ -69,3 +69,29 @@ def test_bench_under_torchrun_uses_rccl(gpu):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 2 and d["value"] > 0
     assert d["config"]["collective"] == "rccl all_gather_into_tensor"
+
+
+def test_bench_self_launch(gpu):
+    """`python bench.py --gpus N` without an external launcher: the parent (no GPU call) starts torch.distributed.run as a
+    child, relays rank 0's JSON line and the exit code.  N=1 forced through --self-launch is what a 1-GPU box can run; the
+    N>1 path is the same code with another --nproc-per-node."""
+    d = _run("--self-launch", "--no-cpu-baseline", "--no-extras", "--batch-per-gpu", "2")
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 2 and d["value"] > 0
+    assert d["config"]["collective"] == "rccl all_gather_into_tensor"
+    assert d["config"]["world_size"] == 1 and d["config"]["rccl_version"]
+    assert d["config"]["launcher"].startswith("bench.py self-launch")
+    assert "roofline_step" in d and 0 < d["roofline_step"]["frac"] < 1
+
+
+def test_bench_roofline_step_and_profile_facts(gpu):
+    """The default line carries the whole-step MFMA roofline and the tracked-profile fields (null unless profiles/ holds a
+    rocprofv3 pass of this very kernel source)."""
+    d = _run("--no-cpu-baseline", "--no-extras")
+    rs = d["roofline_step"]
+    assert rs["bound"] == "mfma" and abs(rs["flops_per_map"] - 2.1307e12) < 2e9
+    assert abs(rs["achieved"] - rs["flops_per_map"] / (d["ms_per_step"] * 1e-3) / 1e12) < 1e-6 * rs["achieved"]
+    r = d["roofline"]
+    for k in ("frac_rocprof", "avg_launch_ms_rocprof", "sustained_clock_ghz", "profile_facts"):
+        assert k in r
+    if r["frac_rocprof"] is not None:
+        assert abs(r["frac_rocprof"] - r["frac"]) < 0.1 and 1.0 < r["sustained_clock_ghz"] < 2.6
