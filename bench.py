@@ -180,8 +180,14 @@ def measure_peaks(dev):
     def mfma16():
         flops[0] = lib.msnet_peak_mfma_f16_16x16(_lib.ptr(dst), 40000, _lib.stream_ptr())
     t_mfma16 = timed(mfma16, 3)
-    return {"hbm_copy_GBs": 2.0 * n / t_copy / 1e6, "mfma_f16_TFLOPs": f32 / t_mfma / 1e9,
-            "mfma_f16_16x16x32_TFLOPs": flops[0] / t_mfma16 / 1e9}
+    out = {"hbm_copy_GBs": 2.0 * n / t_copy / 1e6, "mfma_f16_TFLOPs": f32 / t_mfma / 1e9,
+           "mfma_f16_16x16x32_TFLOPs": flops[0] / t_mfma16 / 1e9}
+    for key, shape in (("mfma_f16_changing_operands_TFLOPs", 0), ("mfma_f16_16x16x32_changing_operands_TFLOPs", 1)):
+        def mfma_r(shape=shape):
+            flops[0] = lib.msnet_peak_mfma_f16_rand(_lib.ptr(dst), 40000, shape, _lib.stream_ptr())
+        t = timed(mfma_r, 3)
+        out[key] = flops[0] / t / 1e9
+    return out
 
 
 def self_launch(n):
@@ -411,15 +417,24 @@ def main():
             print("  per-step ms (sorted): " + " ".join("%.2f" % t for t in per_step), file=sys.stderr)
         if world == 1 and not args.no_extras:
             pk = measure_peaks(dev)
-            line["peaks_measured"] = dict(pk, note="this device, this run: float4 copy of 1 GiB (read + write bytes) and a "
-                                                   "register-only v_mfma_f32_32x32x16_f16 loop on non-zero operands, best of 3-5")
+            line["peaks_measured"] = dict(pk, note="this device, this run: float4 copy of 1 GiB (read + write bytes); register-only "
+                                                   "v_mfma_f32_32x32x16_f16 / 16x16x32 loops on constant small-integer operands and "
+                                                   "(changing_operands) on eight pseudo-random full-mantissa fragments cycled per "
+                                                   "instruction -- the power-limited rate a real kernel can reach; best of 3-5")
             if mfmas:
                 att = pk["mfma_f16_TFLOPs"] / mfmas
+                sus = pk["mfma_f16_changing_operands_TFLOPs"] / mfmas
                 line["roofline"]["peak_attainable"] = att
                 line["roofline"]["frac_attainable"] = achieved / att if att > 0 else None
+                # the rate the chip's power management sustains when every MFMA multiplies fresh full-mantissa operands (the conv
+                # kernels' case: identical instruction streams run 1.5x faster on all-zero data, tools/tools_power_probe.py)
+                line["roofline"]["peak_sustained"] = sus
+                line["roofline"]["frac_sustained"] = achieved / sus if sus > 0 else None
                 if "roofline_step" in line:
                     line["roofline_step"]["peak_attainable"] = att
                     line["roofline_step"]["frac_attainable"] = line["roofline_step"]["achieved"] / att if att > 0 else None
+                    line["roofline_step"]["peak_sustained"] = sus
+                    line["roofline_step"]["frac_sustained"] = line["roofline_step"]["achieved"] / sus if sus > 0 else None
             if "roofline_volume" in line:
                 line["roofline_volume"]["peak_attainable"] = pk["hbm_copy_GBs"]
                 line["roofline_volume"]["frac_attainable"] = line["roofline_volume"]["achieved"] / pk["hbm_copy_GBs"]

@@ -45,7 +45,8 @@ long        msnet_prof_collect(char* buf_host, size_t buf_bytes);
 
 /* fp16-range guard of the split-fp16 kernels (their operands' `hi` halves are fp16: |x| must stay below 65504).  While a
  * device word is registered (per calling thread; NULL unregisters) every conv / transposed-conv epilogue and the NCDHW ->
- * NDHWC conversion of the module input OR 1 into it when they store / read a magnitude >= 65504 (or a non-finite value).
+ * NDHWC conversion of the module input OR a bit into it when they store / read a magnitude >= 65504 (or a non-finite value):
+ * bit 0 = an activation (conv / transposed-conv epilogues), bit 1 = the module input (layout conversion, first-layer loader).
  * The caller zeroes the word, runs the layers, reads it back; ms-nets_amd/hipops.py re-runs the forward on the exact
  * fp32 kernels when it is set.  No reference counterpart: torch's fp32 conv has no such range limit. */
 int msnet_set_overflow_flag(void* device_u32);
@@ -59,7 +60,10 @@ int msnet_set_exact_tails(int on);
  * (0 on error); `scratch` is any device buffer of >= 1 MiB.  Time both with events on `stream`. */
 int    msnet_peak_copy(const void* src, void* dst, size_t bytes, msnet_stream_t stream);
 double msnet_peak_mfma_f16(void* scratch, int iters, msnet_stream_t stream);
-double msnet_peak_mfma_f16_16x16(void* scratch, int iters, msnet_stream_t stream);   /* same, v_mfma_f32_16x16x32_f16 */
+double msnet_peak_mfma_f16_16x16(void* scratch, int iters, msnet_stream_t stream);
+/* The same rate on CHANGING operands (eight pseudo-random A and four B fragments cycled in registers): what the chip's power
+ * management sustains when every MFMA sees fresh data, as in a real kernel.  shape16: 0 = 32x32x16, 1 = 16x16x32. */
+double msnet_peak_mfma_f16_rand(void* scratch, int iters, int shape16, msnet_stream_t stream);   /* same, v_mfma_f32_16x16x32_f16 */
 
 /* ---- matchers: replaces src/cpp/matchers/matchers.cpp:565-580 (libmatchers) ----------------- */
 /* census(left,right,ndisp,wsize) matchers.cpp:232-353.  l,r: u8[H][W]; out: f32[H][W][ndisp];
@@ -165,9 +169,17 @@ int msnet_deconv3d_k3s2_f16s(const float* x, const void* wpk_f16s, const float* 
 int msnet_deconv3d_k3s2(const float* x, const float* wpk, const float* scale, const float* shift,
                         const float* residual, float* y, int N, int D, int H, int W, int Ci, int Co,
                         int relu, msnet_stream_t stream);
+/* The first layer (cbmv_in_planes = 8, gcnet_3dcnn.py:99-101) read straight from the module's NCDHW volume
+ * x: f32[N][8][D][H][W] (the layout cbmv_generator.py:307-308 produces) -> y: NDHWC f32[N][D][H][W][Co], Co = 32 or 64, stride 1,
+ * no residual; split-fp16 MFMA.  Replaces msnet_ncdhw_to_ndhwc + msnet_conv3d_k3_f16s for that layer: the volume is not
+ * copied.  wpk_f16s as for msnet_conv3d_k3_f16s (Ci = 8).  Out-of-range INPUT values raise bit 1 of the overflow word. */
+int msnet_conv3d_k3_c8_ncdhw_f16s(const float* x_ncdhw, const void* wpk_f16s, const float* scale, const float* shift,
+                                  float* y, int N, int D, int H, int W, int Co, int relu, msnet_stream_t stream);
 /* Conv3d(Ci->1, k3, p1, bias=False) head (psmnet_3dcnn.py:112-122 classif*.2), optional "+ add"
- * (cost2 = classif2(out2) + cost1, :146-147).  x: NDHWC; w: f32[1][Ci][3][3][3]; y/add: f32[N][D][H][W]. */
-int msnet_conv3d_k3_cout1(const float* x, const float* w, const float* add, float* y, int N, int D,
+ * (cost2 = classif2(out2) + cost1, :146-147).  x: NDHWC; w: f32[1][Ci][3][3][3]; y/add: f32[N][D][H][W].
+ * y = wscale * conv(x, w) (+ add): the caller may hand over the weights multiplied by a power of two (so that their fp16
+ * `hi` halves are normal numbers on the split-fp16 MFMA) and undo it with wscale; 1 for plain weights. */
+int msnet_conv3d_k3_cout1(const float* x, const float* w, float wscale, const float* add, float* y, int N, int D,
                           int H, int W, int Ci, msnet_stream_t stream);
 
 /* ---- tails ---------------------------------------------------------------------------------- */
@@ -175,8 +187,9 @@ int msnet_conv3d_k3_cout1(const float* x, const float* w, const float* add, floa
 int msnet_softargmin(const float* logits, float* disp, int N, int D, int H, int W, msnet_stream_t stream);
 /* deconv5 (ConvTranspose3d Ci->1, k3, s2, p1, op1, bias) fused with the soft-argmin: the [N][2D][2H][2W]
  * logit volume is never written.  gcnet_3dcnn.py:124-141.  x: NDHWC [N][D][H][W][Ci];
- * w: f32[Ci][1][3][3][3]; bias_host: the scalar bias; disp: f32[N][2H][2W]. */
-int msnet_deconv5_softargmin(const float* x, const float* w, float bias_host, float* disp, int N, int D,
+ * w: f32[Ci][1][3][3][3]; bias_host: the scalar bias; disp: f32[N][2H][2W].
+ * logits = wscale * deconv(x, w) + bias: wscale undoes a power-of-two pre-scale of w (see msnet_conv3d_k3_cout1); 1 for plain weights. */
+int msnet_deconv5_softargmin(const float* x, const float* w, float bias_host, float wscale, float* disp, int N, int D,
                              int H, int W, int Ci, msnet_stream_t stream);
 /* Un-fused deconv5 (stride 2 or the is_quarter_input_size stride-4/op-3 variant, gcnet_3dcnn.py:88-92).
  * logits: f32[N][s*D][s*H][s*W]. */

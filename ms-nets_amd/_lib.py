@@ -30,6 +30,7 @@ SIGNATURES = {
     "msnet_peak_copy": (c_int, [P, P, c_size_t, P]),
     "msnet_peak_mfma_f16": (ctypes.c_double, [P, c_int, P]),
     "msnet_peak_mfma_f16_16x16": (ctypes.c_double, [P, c_int, P]),
+    "msnet_peak_mfma_f16_rand": (ctypes.c_double, [P, c_int, c_int, P]),
     "msnet_census": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "msnet_census_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "msnet_ncc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),
@@ -59,9 +60,10 @@ SIGNATURES = {
     "msnet_pack_deconv_weight_f16s": (c_int, [P, P, c_int, c_int, P]),
     "msnet_deconv3d_k3s2_f16s": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_deconv3d_k3s2": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
-    "msnet_conv3d_k3_cout1": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "msnet_conv3d_k3_c8_ncdhw_f16s": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "msnet_conv3d_k3_cout1": (c_int, [P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_softargmin": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
-    "msnet_deconv5_softargmin": (c_int, [P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "msnet_deconv5_softargmin": (c_int, [P, P, c_float, c_float, P, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_deconv3d_cout1": (c_int, [P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_trilinear_softargmin": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_epe_badx": (c_int, [P, P, c_size_t, c_float, c_float, P, P]),

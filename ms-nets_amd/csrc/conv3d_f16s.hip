@@ -381,6 +381,13 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #ifdef EXP_NO_A_WRITE
                 if (STRIDE == 2) continue;              // diagnostic (wrong numerics): no split, no LDS copy
 #endif
+#ifdef EXP_PRESPLIT
+                if constexpr (SLIDE) {                  // experiment: the input holds split records, a slot is 16 bytes of one verbatim
+                    if (u * LT + lt < PSLOT)
+                        *reinterpret_cast<f32x4*>(lds + pslot * (IH * IW * RB) + (lt / VR) * RB + (lt % VR) * 16 + u * (LT / VR) * RB) = src[u];
+                    continue;
+                }
+#endif
                 if (u * LT + lt < PSLOT) {
                     half4 hi, lo;
 #ifdef EXP_NO_SPLIT
@@ -883,6 +890,13 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #endif
     [[maybe_unused]] int sidx = 0;
     TileCtr ctr = ctr0;
+    // Start stagger: identical persistent workgroups run in lockstep, so all 256 CUs reach their epilogues together and the
+    // 64 KB store bursts of a Co = 64 tile queue on HBM (5.2 K cycles per tile in the per-wave stamps, ~1.2 K when a CU stores
+    // alone).  Delaying the workgroups of phase blockIdx & 3 by phase * stagger spreads the bursts; the loader waves wait at b1.
+    if (a.stagger) {
+        const int nsl = (int)(blockIdx.x & 3u) * a.stagger;
+        for (int q = 0; q < nsl; ++q) __builtin_amdgcn_s_sleep(16);
+    }
     for (int it = 0; it < nitems; ++it) {
         int n, od0, oh0, ow0, chunk, cg;
         coords(ctr, n, od0, oh0, ow0, chunk, cg);
@@ -1580,10 +1594,16 @@ __global__ void pack_weight_c8_f16s_kernel(const float* __restrict__ w, _Float16
     }
 }
 
-template <int NB>
+// NCS = true: the input is the module's NCDHW volume [N][8][D][H][W] itself (the layout cbmv_generator.py:307-308 hands over):
+// a slot's four channels come from four planes (buffer_load_dword per plane, 64 consecutive voxels of a tile row per wave
+// instruction), so the separate NCDHW -> NDHWC pass over the 401 MB volume (0.14 ms, 802 MB of traffic) does not exist on
+// this path.  The fp16-range check of the module input, which that pass carried, is made here on the staged values (bit 1 of
+// the overflow word).  Slots: thread t holds voxels t, t+256, ... of the tile, both channel quads (NL = 2 * ceil(NPOS/256)).
+template <int NB, bool NCS>
 __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(ConvArgs a) {    // (Co = 64: 128 accumulator registers, one workgroup per CU)
     constexpr int TD = 2, TH = 4, TW = 32, ID = TD + 2, IH = TH + 2, IW = TW + 2, NPOS = ID * IH * IW;
-    constexpr int NSLOT = NPOS * 2, NL = (NSLOT + 255) / 256;           // float4 (channel quads) per thread per tile
+    constexpr int NSLOT = NCS ? ((NPOS + 255) / 256) * 512 : NPOS * 2;
+    constexpr int NL = (NSLOT + 255) / 256;                             // float4 (channel quads) per thread per tile
     constexpr int WB = 14 * NB * 2 * 1024;
     __shared__ __attribute__((aligned(16))) unsigned char lds_a[NPOS * 32];
     __shared__ __attribute__((aligned(16))) unsigned char lds_b[WB];
@@ -1601,16 +1621,20 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(Co
     // loader role: slot = u*256 + tid -> (pos = slot >> 1, quad = slot & 1).  Per-slot constants (position in the tile, byte
     // offset from the tile origin) are computed once; an interior tile costs one add + one buffer load per slot.
     const size_t isample = (size_t)a.D * a.H * a.W * 8 * 4;
+    const size_t iplane = (size_t)a.D * a.H * a.W * 4;  // NCS: bytes of one channel plane
     f32x4 av[NL];
     unsigned rel_[NL];                                   // byte offset of the slot from the tile's input origin (d0-1, h0-1, w0-1)
     int dhw_[NL];                                        // (id << 16) | (ih << 8) | iw, or -1 past the tile's end
+    auto slot_pos = [&](int u) { return NCS ? (u >> 1) * 256 + tid : (u * 256 + tid) >> 1; };
+    auto slot_q = [&](int u) { return NCS ? (u & 1) : ((u * 256 + tid) & 1); };
 #pragma unroll
     for (int u = 0; u < NL; ++u) {
-        const int slot = u * 256 + tid, pos = slot >> 1, q = slot & 1;
+        const int pos = slot_pos(u), q = slot_q(u);
         const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
-        rel_[u] = (unsigned)((((id * a.H + ih) * a.W + iw) * 8 + q * 4) * 4);
-        dhw_[u] = slot < NSLOT ? ((id << 16) | (ih << 8) | iw) : -1;
+        rel_[u] = NCS ? (unsigned)(((id * a.H + ih) * a.W + iw) * 4) : (unsigned)((((id * a.H + ih) * a.W + iw) * 8 + q * 4) * 4);
+        dhw_[u] = pos < NPOS ? ((id << 16) | (ih << 8) | iw) : -1;
     }
+    float in_amax = 0.f;                                 // NCS: running max magnitude of the staged module input
     TileCtr ctr, nxt;                                    // current item / the one being fetched
     // (Tile order: w fastest, d slowest.  FETCH_SIZE reports 0.76-1.0 GB per launch for the 0.40 GB input: the two input planes
     // d-neighbours share come back over the fabric a thousand tiles later (Infinity Cache, not necessarily HBM).  Measured
@@ -1622,25 +1646,42 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(Co
     nxt = ctr;
     auto issue_a = [&](const TileCtr& c) {
         const int d0 = c.td * TD, h0 = c.th * TH, w0 = c.tw * TW;
-        const auto rsrc = make_rsrc(a.x + (size_t)c.n * (isample / 4), isample);
-        const unsigned base = (unsigned)(((((long)(d0 - 1) * a.H + (h0 - 1)) * a.W + (w0 - 1)) * 8) * 4);   // may wrap; in-range slots bring it back
+        const unsigned base = (unsigned)(((((long)(d0 - 1) * a.H + (h0 - 1)) * a.W + (w0 - 1)) * (NCS ? 1 : 8)) * 4);   // may wrap; in-range slots bring it back
         const bool interior = d0 >= 1 && d0 - 1 + ID <= a.D && h0 >= 1 && h0 - 1 + IH <= a.H && w0 >= 1 && w0 - 1 + IW <= a.W;
-#pragma unroll
-        for (int u = 0; u < NL; ++u) {
+        auto slot_ok = [&](int u) {
             bool ok = dhw_[u] >= 0;
             if (!interior) {
                 const int gd = d0 - 1 + (dhw_[u] >> 16), gh = h0 - 1 + ((dhw_[u] >> 8) & 255), gw = w0 - 1 + (dhw_[u] & 255);
                 ok = ok && (unsigned)gd < (unsigned)a.D && (unsigned)gh < (unsigned)a.H && (unsigned)gw < (unsigned)a.W;
             }
-            av[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ok ? base + rel_[u] : 0xffffffffu, 0, 0));
+            return ok;
+        };
+        if constexpr (NCS) {
+            // one descriptor per channel plane (the plane offset must not ride in soffset next to an out-of-range voffset)
+            const float* xs = a.x + (size_t)c.n * (isample / 4);
+#pragma unroll
+            for (int u = 0; u < NL; ++u) {
+                const unsigned off = slot_ok(u) ? base + rel_[u] : 0xffffffffu;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const auto rs = make_rsrc(xs + (size_t)((u & 1) * 4 + k) * (iplane / 4), iplane);
+                    av[u][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, 0, 0));
+                }
+            }
+        } else {
+            const auto rsrc = make_rsrc(a.x + (size_t)c.n * (isample / 4), isample);
+#pragma unroll
+            for (int u = 0; u < NL; ++u)
+                av[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, slot_ok(u) ? base + rel_[u] : 0xffffffffu, 0, 0));
         }
     };
     auto write_a = [&]() {
 #pragma unroll
         for (int u = 0; u < NL; ++u) {
-            const int slot = u * 256 + tid, pos = slot >> 1, q = slot & 1;
-            if (slot < NSLOT) {
+            const int pos = slot_pos(u), q = slot_q(u);
+            if (pos < NPOS) {
                 half4 hi, lo;
+                if constexpr (NCS) in_amax = fmaxf(fmaxf(in_amax, fmaxf(fabsf(av[u][0]), fabsf(av[u][1]))), fmaxf(fabsf(av[u][2]), fabsf(av[u][3])));
                 split4(av[u], hi, lo);
                 const int sw = ((pos >> 3) & 1) * 16;
                 *reinterpret_cast<half4*>(lds_a + pos * 32 + sw + q * 8) = hi;
@@ -1721,7 +1762,11 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(Co
             for (int b = 0; b < 2 * NB; ++b) {
                 unsigned off; bool rowok; int wlim; float sc, sh; f32x16 v;
                 block(b, off, rowok, wlim, sc, sh, v);
+#ifdef EXP_PRESPLIT
+                epilogue_store_split<32>(v, zero, sc, sh, rs_y, sr_lane_offset(off, r), 0, a.Co * 4, a.relu, [&](int, int lw) { return rowok && lw < wlim; }, r, a.oflag);
+#else
                 epilogue_store<32>(v, zero, sc, sh, rs_y, off, 0, a.Co * 4, a.relu, [&](int, int lw) { return rowok && lw < wlim; }, a.oflag);
+#endif
             }
         } else {
             const auto rs_res = make_rsrc(a.res + (size_t)n * (osample / 4), osample);
@@ -1734,9 +1779,14 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(Co
             }
         }
     }
+    if constexpr (NCS) {
+        // NaN: v_max drops it, so a NaN input would pass the magnitude test -- but it poisons the outputs, whose epilogue
+        // check (!(amax < max)) catches it.  inf and large values are caught here.
+        if (a.oflag && !(in_amax < kF16Max)) atomicOr(a.oflag, 2u);
+    }
 }
 
-template <int NB>
+template <int NB, bool NCS = false>
 static int launch_c8_f16s(const char* name, ConvArgs a, hipStream_t s) {
     a.ntd = cdiv(a.OD, 2); a.nth = cdiv(a.OH, 4); a.ntw = cdiv(a.OW, 32);
     const size_t ntiles = (size_t)a.N * a.ntd * a.nth * a.ntw;
@@ -1748,7 +1798,7 @@ static int launch_c8_f16s(const char* name, ConvArgs a, hipStream_t s) {
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
                    4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((conv3d_c8_f16s_kernel<NB>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv3d_c8_f16s_kernel<NB, NCS>), dim3((unsigned)nblk), dim3(256), 0, s, a);
     return check_launch(name);
 }
 
@@ -1924,6 +1974,9 @@ static int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
         return fail("%s: a sample exceeds the range of the kernel's buffer descriptors (2 GB in, 4 GB out; use the fp32 path)", name);
     const size_t nblk = ntiles < (size_t)num_cus() ? ntiles : (size_t)num_cus();
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
+#ifdef EXP_STAGGER
+    if (const char* e = getenv("MSNET_EXP_STAGGER")) a.stagger = atoi(e);
+#endif
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
                    4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
     hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB, SWZ, KS, RESB, STRIDE, false, LW>), dim3((unsigned)nblk), dim3(256 + 64 * LW), 0, s, a);
@@ -2053,6 +2106,22 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
         if (rc >= 0) return rc;
     }
     return launch_f16s<2, 4, 32, 32, 2, 1, false, 2, false>("conv3d_s1_f16s_co32", a, s);
+}
+
+// First layer straight from the module's NCDHW volume (8 planes): conv3d_c8_f16s_kernel<NB, true>.  Always the tiled kernel
+// (no small-layer direct path), so the summation order does not depend on the size.
+extern "C" int msnet_conv3d_k3_c8_ncdhw_f16s(const float* x_ncdhw, const void* wpk_f16s, const float* scale, const float* shift,
+                                             float* y, int N, int D, int H, int W, int Co, int relu, msnet_stream_t stream) {
+    if (!x_ncdhw || !wpk_f16s || !y) return fail("msnet_conv3d_k3_c8_ncdhw_f16s: null pointer");
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_conv3d_k3_c8_ncdhw_f16s: empty input");
+    if (Co != 32 && Co != 64) return fail("msnet_conv3d_k3_c8_ncdhw_f16s: Co=%d (32 or 64)", Co);
+    ConvArgs a{};
+    a.x = x_ncdhw; a.wpk = reinterpret_cast<const f32x4*>(wpk_f16s); a.scale = scale; a.shift = shift; a.res = nullptr; a.y = y;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = 8; a.Co = Co; a.relu = relu; a.oflag = overflow_flag();
+    a.OD = D; a.OH = H; a.OW = W;
+    hipStream_t s = (hipStream_t)stream;
+    if (Co == 64) return launch_c8_f16s<2, true>("conv3d_s1_c8_f16s", a, s);
+    return launch_c8_f16s<1, true>("conv3d_s1_c8_f16s", a, s);
 }
 
 // Ci = 64 with Co = 32 / 64 has the tiled kernel; the other shapes (and any small layer) run on the direct kernel.

@@ -77,9 +77,78 @@ __global__ __launch_bounds__(256) void peak_mfma_f16_16x16_kernel(float* __restr
     if (s == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// The loops above multiply the SAME two operand registers over and over: nothing toggles on the operand paths, which
+// understates what the chip's power management does to a real kernel (the conv kernels run 1.5x faster on all-zero data than
+// on random data with the identical instruction stream, tools/tools_power_probe.py).  The *_rand loops cycle through eight
+// different pseudo-random A fragments and four B fragments (all in registers, every MFMA sees operands that differ from the
+// previous one's in most bits): the dense fp16 MFMA rate the chip SUSTAINS on changing data -- the fair ceiling for a kernel
+// whose operands are fresh for every instruction.
+__device__ __forceinline__ half8_p rand_frag(unsigned& st) {
+    half8_p v;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        st = st * 1664525u + 1013904223u;
+        v[k] = (_Float16)(((float)(st >> 8) * (1.0f / 16777216.0f) - 0.5f) * 4.0f);
+    }
+    return v;
+}
+
+template <bool S16>
+__global__ __launch_bounds__(256) void peak_mfma_f16_rand_kernel(float* __restrict__ out, int iters) {
+    unsigned st = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u;
+    half8_p a[8], b[4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a[k] = rand_frag(st);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) b[k] = rand_frag(st);
+    float s = 0.f;
+    if constexpr (!S16) {
+        f32x16 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[(j * 3 + 1) & 7], b[j & 3], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) s += acc[j][e];
+    } else {
+        f32x4_p acc[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[j][e] = 0.f;
+        for (int it = 0; it < iters; ++it) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[(j * 3 + 1) & 7], b[j & 3], acc[j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += acc[j][e];
+    }
+    if (s == 12345.678f) out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 }  // namespace msnet
 
 using namespace msnet;
+
+/* fp16 MFMA rate on CHANGING operands (shape16 = 0: v_mfma_f32_32x32x16_f16, 1: v_mfma_f32_16x16x32_f16); returns the FLOPs of the call */
+extern "C" double msnet_peak_mfma_f16_rand(void* scratch, int iters, int shape16, msnet_stream_t stream) {
+    if (!scratch || iters <= 0) { fail("msnet_peak_mfma_f16_rand: bad arguments"); return 0.0; }
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int blocks = cus * 2;
+    if (shape16) hipLaunchKernelGGL(peak_mfma_f16_rand_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)scratch, iters);
+    else hipLaunchKernelGGL(peak_mfma_f16_rand_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float*)scratch, iters);
+    if (check_launch("msnet_peak_mfma_f16_rand")) return 0.0;
+    return (double)blocks * 4.0 * iters * 8.0 * 2.0 * 32 * 32 * 16;       // both shapes: 8 x 32x32x16 = 16 x 16x16x32 FLOPs per iteration
+}
 
 extern "C" int msnet_peak_copy(const void* src, void* dst, size_t bytes, msnet_stream_t stream) {
     if (!src || !dst || bytes < 16) return fail("msnet_peak_copy: bad arguments");

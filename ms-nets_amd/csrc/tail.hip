@@ -98,7 +98,7 @@ struct SliceStage {
 // kernel was bound by those reads (896 LDS cycles per wave-slice against 864 FMA issue slots), not by the VALU.
 template <int CI, bool WRITE_LOGITS, int RT, int CPT>
 __global__ __launch_bounds__(RT * 32) void deconv5_tail_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                               float bias, float* __restrict__ out, int N, int D, int H,
+                                                               float bias, float wsc, float* __restrict__ out, int N, int D, int H,
                                                                int W, int nth, int ntw) {
     constexpr int TH = RT * CPT, TW = 32, IH = TH + 1, IW = TW + 1, PS = CI + 4, NT = RT * 32;
     __shared__ __attribute__((aligned(16))) float lds[IH * IW * PS];
@@ -181,14 +181,14 @@ __global__ __launch_bounds__(RT * 32) void deconv5_tail_kernel(const float* __re
 #pragma unroll
                     for (int c = 0; c < 4; ++c) {
                         const size_t pix = (size_t)(2 * (h + j) + (c >> 1)) * OW + (2 * wq + (c & 1));
-                        if (P >= 1) out[((size_t)n * OD + (2 * P - 1)) * OH * OW + pix] = carry[j][c] + p[j][0][c] + bias;
-                        if (P < D)  out[((size_t)n * OD + 2 * P) * OH * OW + pix] = p[j][1][c] + bias;
+                        if (P >= 1) out[((size_t)n * OD + (2 * P - 1)) * OH * OW + pix] = (carry[j][c] + p[j][0][c]) * wsc + bias;
+                        if (P < D)  out[((size_t)n * OD + 2 * P) * OH * OW + pix] = p[j][1][c] * wsc + bias;
                     }
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const float lo = carry[j][c] + p[j][0][c] + bias, hi = p[j][1][c] + bias;
+                    const float lo = (carry[j][c] + p[j][0][c]) * wsc + bias, hi = p[j][1][c] * wsc + bias;
                     if (P >= 1 && P < D) sa[j][c].push2(lo, (float)(2 * P - 1), hi, (float)(2 * P));
                     else if (P < D)      sa[j][c].push(hi, (float)(2 * P));
                     else                 sa[j][c].push(lo, (float)(2 * P - 1));
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(RT * 32) void deconv5_tail_kernel(const float* __re
 // neighbours (h+1, w+1) are inside it; tiles overlap by one row / column (18 % extra MFMA work, no halo exchange).
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                                float bias, float* __restrict__ out, int N, int D, int H,
+                                                                float bias, float wsc, float* __restrict__ out, int N, int D, int H,
                                                                 int W, int nth, int ntw) {
     constexpr int CI = 32, TH = 8, TW = 32, UH = 7, UW = 31, PS = CI + 4, TS = 33, NT = 256;
     // the tap partials reuse the slice buffer (its fragments are in registers by then): 37 KB per workgroup, so the
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const float lo = carry[q] + p[0][q] + bias, hi = p[1][q] + bias;
+            const float lo = (carry[q] + p[0][q]) * wsc + bias, hi = p[1][q] * wsc + bias;
             if (P >= 1 && P < D) sa[q].push2(lo, (float)(2 * P - 1), hi, (float)(2 * P));
             else if (P < D)      sa[q].push(hi, (float)(2 * P));
             else                 sa[q].push(lo, (float)(2 * P - 1));
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const
 // adds its kd=2 partial to out[P-1] (finishing it), kd=1 to out[P] and kd=0 to out[P+1].
 // ---------------------------------------------------------------------------------------------
 template <int CI>
-__global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict__ x, const float* __restrict__ w, float wsc,
                                                          const float* __restrict__ add, float* __restrict__ y, int N,
                                                          int D, int H, int W, int nth, int ntw) {
     constexpr int TH = 8, TW = 32, IH = TH + 2, IW = TW + 2, PS = CI + 4;
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict
         }
         if (P >= 1 && live) {
             const size_t idx = (((size_t)n * D + (P - 1)) * H + h) * W + wq;
-            float v = r1 + q[2];
+            float v = (r1 + q[2]) * wsc;
             if (add) v += add[idx];
             y[idx] = v;
         }
@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict
 // 27 tap partials T[voxel][tap] are computed once, parked in LDS, and each output voxel (h, w) adds, for kd = 0,1,2, the nine
 // partials T[(h+kh-1, w+kw-1)][kd,kh,kw] of its 3x3 neighbourhood; kd = 2 finishes out[P-1], kd = 1 goes to out[P], kd = 0 to
 // out[P+1].  A workgroup multiplies 8 x 32 input voxels per slice (origin h0-1, w0-1) and finishes the inner 6 x 30 outputs.
-__global__ __launch_bounds__(256) void conv_cout1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void conv_cout1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, float wsc,
                                                               const float* __restrict__ add, float* __restrict__ y, int N,
                                                               int D, int H, int W, int nth, int ntw) {
     constexpr int CI = 32, TH = 8, TW = 32, UH = 6, UW = 30, PS = CI + 4, TS = 33, NT = 256;
@@ -524,7 +524,7 @@ __global__ __launch_bounds__(256) void conv_cout1_mfma_kernel(const float* __res
         }
         if (P >= 1 && live) {
             const size_t idx = (((size_t)n * D + (P - 1)) * H + h) * W + wq;
-            float v = r1 + q[2];
+            float v = (r1 + q[2]) * wsc;
             if (add) v += add[idx];
             y[idx] = v;
         }
@@ -642,7 +642,7 @@ extern "C" int msnet_softargmin(const float* logits, float* disp, int N, int D, 
     return check_launch("msnet_softargmin");
 }
 
-extern "C" int msnet_deconv5_softargmin(const float* x, const float* w, float bias, float* disp, int N, int D, int H,
+extern "C" int msnet_deconv5_softargmin(const float* x, const float* w, float bias, float wscale, float* disp, int N, int D, int H,
                                         int W, int Ci, msnet_stream_t stream) {
     if (!x || !w || !disp) return fail("msnet_deconv5_softargmin: null pointer");
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_deconv5_softargmin: empty input");
@@ -656,9 +656,9 @@ extern "C" int msnet_deconv5_softargmin(const float* x, const float* w, float bi
     LaunchScope ls("deconv5_softargmin", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + 4.0 * N * H * W));
     if (valu)
         hipLaunchKernelGGL((deconv5_tail_kernel<32, false, RT, CPT>), dim3((unsigned)(N * nth * ntw)), dim3(RT * 32), 0, s, x, w,
-                           bias, disp, N, D, H, W, nth, ntw);
+                           bias, wscale, disp, N, D, H, W, nth, ntw);
     else
-        hipLaunchKernelGGL(deconv5_tail_mfma_kernel, dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, bias, disp, N, D, H, W,
+        hipLaunchKernelGGL(deconv5_tail_mfma_kernel, dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, bias, wscale, disp, N, D, H, W,
                            nth, ntw);
     return check_launch("msnet_deconv5_softargmin");
 }
@@ -674,7 +674,7 @@ extern "C" int msnet_deconv3d_cout1(const float* x, const float* w, float bias, 
         const int nth = cdiv(H, 8), ntw = cdiv(W, 32);
         LaunchScope ls("deconv5_logits", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + 8.0 * vox));
         hipLaunchKernelGGL((deconv5_tail_kernel<32, true, 8, 1>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w,
-                           bias, logits, N, D, H, W, nth, ntw);
+                           bias, 1.f, logits, N, D, H, W, nth, ntw);
         return check_launch("msnet_deconv3d_cout1");
     }
     const size_t total = (size_t)vox * stride * stride * stride;
@@ -684,7 +684,7 @@ extern "C" int msnet_deconv3d_cout1(const float* x, const float* w, float bias, 
     return check_launch("msnet_deconv3d_cout1");
 }
 
-extern "C" int msnet_conv3d_k3_cout1(const float* x, const float* w, const float* add, float* y, int N, int D, int H,
+extern "C" int msnet_conv3d_k3_cout1(const float* x, const float* w, float wscale, const float* add, float* y, int N, int D, int H,
                                      int W, int Ci, msnet_stream_t stream) {
     if (!x || !w || !y) return fail("msnet_conv3d_k3_cout1: null pointer");
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_conv3d_k3_cout1: empty input");
@@ -694,11 +694,11 @@ extern "C" int msnet_conv3d_k3_cout1(const float* x, const float* w, const float
     LaunchScope ls("conv3d_cout1", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + vox * (add ? 2 : 1)));
     if (exact_tails()) {
         const int nth = cdiv(H, 8), ntw = cdiv(W, 32);
-        hipLaunchKernelGGL((conv_cout1_kernel<32>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, add, y, N, D, H,
+        hipLaunchKernelGGL((conv_cout1_kernel<32>), dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, wscale, add, y, N, D, H,
                            W, nth, ntw);
     } else {
         const int nth = cdiv(H, 6), ntw = cdiv(W, 30);
-        hipLaunchKernelGGL(conv_cout1_mfma_kernel, dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, add, y, N, D, H, W,
+        hipLaunchKernelGGL(conv_cout1_mfma_kernel, dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, wscale, add, y, N, D, H, W,
                            nth, ntw);
     }
     return check_launch("msnet_conv3d_k3_cout1");

@@ -20,6 +20,13 @@ from . import hipops
 from .net_init import net_init
 
 
+# First layer straight from the NCDHW volume (msnet_conv3d_k3_c8_ncdhw_f16s) instead of layout conversion + NDHWC first layer.
+# Measured at 960x544x192 (profiles/r03c_*): the conversion pass (0.14 ms, 802 MB) disappears but the first layer goes from
+# 0.65 to 0.83 ms -- a 34-voxel tile row is 136 bytes in each of 8 planes (two cache lines each) instead of 1088 contiguous
+# bytes, 1.7x the L1 fills and 4.5x the load instructions -- so it is NOT the default; it saves 401 MB of activation memory.
+FUSE_INPUT_LAYOUT = os.environ.get("MSNET_FUSE_INPUT_LAYOUT", "0") == "1"
+
+
 def _convbn(cin, cout, stride):
     return nn.Sequential(nn.Conv3d(cin, cout, 3, stride=stride, padding=1, bias=False), nn.BatchNorm3d(cout))
 
@@ -89,8 +96,10 @@ class GCNet_CostVolumeAggre(nn.Module):
         self.__dict__.pop("_graphs", None)        # captured HIP graphs hold the old packed weights
 
     def _plans(self, precision):
-        key = hipops.state_key(self) + (precision,)
+        key = hipops.state_key(self)
         if self._plan is None or key != self._plan_key:
+            self._plan, self._plan_key = {}, key           # one plan per precision; all dropped when the parameters change
+        if precision not in self._plan:
             P = lambda *a, **k: hipops.ConvBNPlan(*a, precision=precision, **k)      # noqa: E731
             plan = {"conv3dbn_1": P(*self.conv3dbn_1), "conv3dbn_2": P(*self.conv3dbn_2)}
             for b in ("block_3d_1", "block_3d_2", "block_3d_3", "block_3d_4"):
@@ -100,9 +109,10 @@ class GCNet_CostVolumeAggre(nn.Module):
             for dname in ("deconvbn1", "deconvbn2", "deconvbn3", "deconvbn4"):
                 plan[dname] = P(*getattr(self, dname), transposed=True)
             plan["deconv5.w"] = self.deconv5.weight.detach().float().contiguous()
+            plan["deconv5.wps"], plan["deconv5.wsc"] = hipops.pow2_prescale(self.deconv5.weight)   # fused tail (split-fp16 MFMA)
             plan["deconv5.b"] = float(self.deconv5.bias.detach().float().item())
-            self._plan, self._plan_key = plan, key
-        return self._plan
+            self._plan[precision] = plan
+        return self._plan[precision]
 
     # ---- forward -----------------------------------------------------------------------------------
     def forward(self, cv, taps=None):
@@ -142,8 +152,13 @@ class GCNet_CostVolumeAggre(nn.Module):
             return tap(name, hipops.deconv3d_k3s2(x, p.wpk, p.scale, p.shift, p.co, relu=True, residual=skip, f16s=p.f16s))
 
         with torch.no_grad():
-            x = hipops.ncdhw_to_ndhwc(cv)
-            x = tap("conv3dbn_1", conv(x, "conv3dbn_1"))
+            p1 = pl["conv3dbn_1"]
+            if p1.f16s and cv.shape[1] == 8 and p1.co in (32, 64) and FUSE_INPUT_LAYOUT:
+                # the first layer reads the NCDHW volume itself: no layout-conversion pass over the 401 MB
+                x = tap("conv3dbn_1", hipops.conv3d_c8_ncdhw(cv, p1.wpk, p1.scale, p1.shift, p1.co, relu=True))
+            else:
+                x = hipops.ncdhw_to_ndhwc(cv)
+                x = tap("conv3dbn_1", conv(x, "conv3dbn_1"))
             res_l20 = x = tap("conv3dbn_2", conv(x, "conv3dbn_2"))
             res_l23 = x = block(x, "block_3d_1", 2)
             res_l26 = x = block(x, "block_3d_2", 2)
@@ -157,7 +172,7 @@ class GCNet_CostVolumeAggre(nn.Module):
             depth = s * x.shape[1]
             assert depth == self.maxdisp, "%d != %d" % (depth, self.maxdisp)   # gcnet_3dcnn.py:135
             if s == 2 and taps is None:
-                return hipops.deconv5_softargmin(x, pl["deconv5.w"], pl["deconv5.b"])
+                return hipops.deconv5_softargmin(x, pl["deconv5.wps"], pl["deconv5.b"], pl["deconv5.wsc"])
             logits = hipops.deconv3d_cout1(x, pl["deconv5.w"], pl["deconv5.b"], stride=s)
             if taps is not None:
                 taps["deconv5"] = logits.unsqueeze(1)

@@ -140,6 +140,18 @@ def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16
     return y
 
 
+def conv3d_c8_ncdhw(x, wpk, scale, shift, co, relu=False):
+    """First layer straight from the NCDHW volume x [N,8,D,H,W] (no layout-conversion pass) -> NDHWC [N,D,H,W,co]; split-fp16."""
+    x = require_gpu_f32(x, "x")
+    n, c, d, h, w = x.shape
+    if c != 8:
+        raise ValueError("conv3d_c8_ncdhw takes an 8-channel volume (got %d)" % c)
+    y = _new((n, d, h, w, co), x.device)
+    check(_lib.load().msnet_conv3d_k3_c8_ncdhw_f16s(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(y), n, d, h, w, co, int(relu),
+                                                    stream_ptr()), "msnet_conv3d_k3_c8_ncdhw_f16s")
+    return y
+
+
 def deconv3d_k3s2(x, wpk, scale, shift, co, relu=False, residual=None, f16s=False):
     x = require_gpu_f32(x, "x")
     n, d, h, w, ci = x.shape
@@ -154,8 +166,20 @@ def deconv3d_k3s2(x, wpk, scale, shift, co, relu=False, residual=None, f16s=Fals
     return y
 
 
-def conv3d_k3_cout1(x, w, add=None):
-    """Conv3d(Ci->1) head.  x NDHWC, w [1,Ci,3,3,3] -> [N,D,H,W]."""
+def pow2_prescale(w):
+    """(w * 2^k, 2^-k) with k chosen so that max|w * 2^k| lies in [2^8, 2^9): the split-fp16 kernels' weights stay fp16-normal
+    (22-bit hi + lo) whatever the checkpoint's scale; the kernel multiplies its result by 2^-k (exact).  One host sync."""
+    w = w.detach().float().contiguous()
+    m = float(w.abs().max())
+    if not (m > 0) or m != m or m == float("inf"):
+        return w, 1.0
+    import math
+    k = max(-100, min(100, 8 - math.floor(math.log2(m))))
+    return (w * (2.0 ** k)).contiguous(), 2.0 ** -k
+
+
+def conv3d_k3_cout1(x, w, add=None, wscale=1.0):
+    """Conv3d(Ci->1) head.  x NDHWC, w [1,Ci,3,3,3] -> [N,D,H,W].  y = wscale * conv(x, w) (+ add), see pow2_prescale."""
     x = require_gpu_f32(x, "x")
     w = require_gpu_f32(w, "weight")
     n, d, h, wd, ci = x.shape
@@ -164,7 +188,7 @@ def conv3d_k3_cout1(x, w, add=None):
         add = require_gpu_f32(add, "add")
         if add.shape != y.shape:
             raise ValueError("add shape mismatch")
-    check(_lib.load().msnet_conv3d_k3_cout1(ptr(x), ptr(w), ptr(add), ptr(y), n, d, h, wd, ci, stream_ptr()),
+    check(_lib.load().msnet_conv3d_k3_cout1(ptr(x), ptr(w), float(wscale), ptr(add), ptr(y), n, d, h, wd, ci, stream_ptr()),
           "msnet_conv3d_k3_cout1")
     return y
 
@@ -177,13 +201,14 @@ def softargmin(logits):
     return disp
 
 
-def deconv5_softargmin(x, w, bias):
-    """Fused ConvTranspose3d(Ci->1,k3,s2,p1,op1,bias) + softmax(D) + sum d*p.  x NDHWC -> [N,2H,2W]."""
+def deconv5_softargmin(x, w, bias, wscale=1.0):
+    """Fused ConvTranspose3d(Ci->1,k3,s2,p1,op1,bias) + softmax(D) + sum d*p.  x NDHWC -> [N,2H,2W].
+    logits = wscale * deconv(x, w) + bias, see pow2_prescale."""
     x = require_gpu_f32(x, "x")
     w = require_gpu_f32(w, "weight")
     n, d, h, wd, ci = x.shape
     disp = torch.empty((n, 2 * h, 2 * wd), device=x.device, dtype=torch.float32)
-    check(_lib.load().msnet_deconv5_softargmin(ptr(x), ptr(w), float(bias), ptr(disp), n, d, h, wd, ci, stream_ptr()),
+    check(_lib.load().msnet_deconv5_softargmin(ptr(x), ptr(w), float(bias), float(wscale), ptr(disp), n, d, h, wd, ci, stream_ptr()),
           "msnet_deconv5_softargmin")
     return disp
 
@@ -258,7 +283,8 @@ def _range_fallback(module, run, word):
     ACTIVATION (a property of the weights -- it would recur): the module stays on fp32 until its parameters change or
     invalidate_plans().  Raised only by the module INPUT (one out-of-range / NaN / inf voxel in this sample): this call only,
     so one bad sample in a serving loop does not move the module onto the slower path for good."""
-    sticky = bool(word & RangeGuard.ACTIVATION)
+    # (a bad input usually drags activations out of range with it: only a trip WITHOUT the input bit is the weights' doing)
+    sticky = not (word & RangeGuard.INPUT)
     warnings.warn("msnet: %s left the fp16 range (|x| >= 65504) of the split-fp16 conv kernels; this forward was repeated on the "
                   "exact fp32 MFMA kernels%s" % ("an activation" if sticky else "the module input",
                                                  ", which this module now keeps using" if sticky else " (this call only)"),
@@ -351,11 +377,12 @@ def _graphed_forward(module, run, graph_key):
             finally:
                 if guard is not None:
                     guard.__exit__()
-        g.update(graph=graph, out=out, guard=guard, arena=arena)
+        # the graph also bakes in the addresses of the packed weights: pin the plan it was captured with
+        g.update(graph=graph, out=out, guard=guard, arena=arena, plan=module._plan.get(precision) if isinstance(module._plan, dict) else None)
     g["graph"].replay()
     word = g["guard"].word() if g["guard"] is not None else 0
     if word:
-        if word & RangeGuard.ACTIVATION:
+        if not (word & RangeGuard.INPUT):
             graphs.clear()
         module.use_graph = False
         try:

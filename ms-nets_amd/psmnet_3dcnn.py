@@ -82,8 +82,10 @@ class PSMNet_CostVolumeAggre(nn.Module):
         self.__dict__.pop("_graphs", None)        # captured HIP graphs hold the old packed weights
 
     def _plans(self, precision):
-        key = hipops.state_key(self) + (precision,)
+        key = hipops.state_key(self)
         if self._plan is None or key != self._plan_key:
+            self._plan, self._plan_key = {}, key           # one plan per precision; all dropped when the parameters change
+        if precision not in self._plan:
             P = lambda *a, **k: hipops.ConvBNPlan(*a, precision=precision, **k)      # noqa: E731
             pl = {"dres0.0": P(*self.dres0[0]), "dres0.2": P(*self.dres0[2]),
                   "dres1.0": P(*self.dres1[0]), "dres1.2": P(*self.dres1[2])}
@@ -98,9 +100,9 @@ class PSMNet_CostVolumeAggre(nn.Module):
             for c in ("classif1", "classif2", "classif3"):
                 seq = getattr(self, c)
                 pl[c + ".0"] = P(*seq[0])
-                pl[c + ".2"] = seq[2].weight.detach().float().contiguous()
-            self._plan, self._plan_key = pl, key
-        return self._plan
+                pl[c + ".2"], pl[c + ".2.wsc"] = hipops.pow2_prescale(seq[2].weight)
+            self._plan[precision] = pl
+        return self._plan[precision]
 
     def _trunk(self, cost, taps, precision):
         pl = self._plans(precision)
@@ -131,8 +133,12 @@ class PSMNet_CostVolumeAggre(nn.Module):
             out = deconv(post, name + ".conv6", False, skip)
             return out, pre, post
 
-        x = hipops.ncdhw_to_ndhwc(cost)
-        c0 = conv(conv(x, "dres0.0"), "dres0.2")
+        p0 = pl["dres0.0"]
+        from .gcnet_3dcnn import FUSE_INPUT_LAYOUT
+        if FUSE_INPUT_LAYOUT and p0.f16s and cost.shape[1] == 8 and p0.co in (32, 64):      # the MS volume: first layer straight from NCDHW
+            c0 = conv(hipops.conv3d_c8_ncdhw(cost, p0.wpk, p0.scale, p0.shift, p0.co, relu=True), "dres0.2")
+        else:
+            c0 = conv(conv(hipops.ncdhw_to_ndhwc(cost), "dres0.0"), "dres0.2")
         cost0 = tap("cost0", conv(conv(c0, "dres1.0"), "dres1.2", relu=False, residual=c0))
         out1, pre1, post1 = hour(cost0, "dres2", None, None, cost0)
         tap("out1", out1)
@@ -140,9 +146,9 @@ class PSMNet_CostVolumeAggre(nn.Module):
         tap("out2", out2)
         out3, _, _ = hour(out2, "dres4", pre1, post2, cost0)
         tap("out3", out3)
-        cost1 = hipops.conv3d_k3_cout1(conv(out1, "classif1.0"), pl["classif1.2"])
-        cost2 = hipops.conv3d_k3_cout1(conv(out2, "classif2.0"), pl["classif2.2"], add=cost1)
-        cost3 = tap("cost3", hipops.conv3d_k3_cout1(conv(out3, "classif3.0"), pl["classif3.2"], add=cost2))
+        cost1 = hipops.conv3d_k3_cout1(conv(out1, "classif1.0"), pl["classif1.2"], wscale=pl["classif1.2.wsc"])
+        cost2 = hipops.conv3d_k3_cout1(conv(out2, "classif2.0"), pl["classif2.2"], add=cost1, wscale=pl["classif2.2.wsc"])
+        cost3 = tap("cost3", hipops.conv3d_k3_cout1(conv(out3, "classif3.0"), pl["classif3.2"], add=cost2, wscale=pl["classif3.2.wsc"]))
         return cost1, cost2, cost3
 
     def _check(self, cost):

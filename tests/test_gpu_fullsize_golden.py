@@ -4,12 +4,12 @@ aggregator, psmnet_3dcnn.py:126-179), for random-init weights and for `peaky` (t
 (recipes.FULL_CASES; produced in the build container by tests/golden/make_fullsize_golden.py).
 
 Gates per case (every one can fail on its own):
-  T   every sampled activation (65 536 strided values per tapped layer) vs the reference's samples: <= 1e-5 of the layer's
+  T   every sampled activation (65 536 strided values per tapped layer) vs the reference's samples: <= 5e-6 of the layer's
       magnitude -- this includes the logits (G1 of the config-#3 test, here pinned to the reference);
   F   flat gate: max |disp - reference| <= 1e-3 wherever the case is well conditioned (see below);
   K   conditioning-aware gate for every pixel: |disp - reference| <= 1e-3 + kappa_i * (G1_BOUND * max|logit| + eps_tail),
       kappa_i = sum_d |d - disp_i| p_d (first-order sensitivity of pixel i's soft-argmin to a logit perturbation) computed
-      in fp64 from the HIP logits.  The tolerance is built from the G1 BOUND (1e-5 relative), never from the measured error.
+      in fp64 from the HIP logits.  The tolerance is built from the G1 BOUND (5e-6 relative), never from the measured error.
 
 "Well conditioned" = random-init MS-GCNet (logits within +-6, kappa <= 54): there F holds for the whole map.  With a
 multi-modal peaky softmax (logits ~ +-100, kappa up to 95) a relative logit difference of 1e-6 -- fp32 summation-order noise
@@ -28,8 +28,8 @@ import recipes
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 DISP_TOL = 1e-3
-TAP_TOL = 1e-5          # relative to the layer's max magnitude (the reference's samples)
-G1_BOUND = 1e-5         # bound on the relative logit error the K gate is built from (== TAP_TOL on the logit tap)
+TAP_TOL = 5e-6          # relative to the layer's max magnitude (the reference's samples); measured <= 2.3e-6
+G1_BOUND = 5e-6         # bound on the relative logit error the K gate is built from (== TAP_TOL on the logit tap)
 KAPPA_FLAT = 1.0        # pixels at least this well conditioned must meet the flat 1e-3 in every case
 
 
@@ -115,14 +115,14 @@ def test_fullsize_vs_reference(gpu, name):
           % (name, float(err.max()), float(err_t.max()), 100 * frac_flat, float(kappa.median()), float(kappa.max()), lmax,
              float((err / tol).max()), float(tol.median()), KAPPA_FLAT, 100 * float(well.float().mean()),
              float(err[well].max()) if bool(well.any()) else 0.0, worst_tap))
-    assert float(disp.min()) >= 0 and float(disp.max()) <= case["maxdisp"] - 1
+    assert float(disp.min()) >= 0 and float(disp.max()) <= case["maxdisp"] - 1 + DISP_TOL      # (sum p can round to 1 + 1 ulp)
     assert float((err - tol).max()) <= 0, "K gate"
     assert float((err_t - tol).max()) <= 0, "K gate (un-fused tail)"
     if bool(well.any()):
         assert float(err[well].max()) <= DISP_TOL, "flat gate on the well-conditioned pixels"
     if not case.get("peaky") and case["model"] == "gcnet":
         assert float(err.max()) <= DISP_TOL, "flat gate"
-    assert frac_flat >= 0.90
+    assert frac_flat >= 0.95
     # ---- the MS-volume case also runs end to end from the two images through the HIP volume build
     if pair is not None:
         from msnets_amd import cbmv_generator as cg
