@@ -20,6 +20,7 @@
 // of the reference's result.
 #include <stdlib.h>
 
+#include <map>
 #include <mutex>
 #include <type_traits>
 
@@ -538,6 +539,12 @@ __global__ __launch_bounds__(256, 3) void features4_kernel(FastArgs a, int zbase
     }
 }
 // ------------------------------------------------------------------------------------------------ host
+static int band_ls(int Wb) {
+    int LS = Wb + 1;
+    while (LS % 8 != 4) ++LS;
+    return LS;
+}
+
 bool volume_fast_supported(const msnet_volume_params& p, int Hb, int Wb, int nd) {
     if (p.censw != kCW || p.nccw != kNW || p.sobelw != kSW || p.sadw != kZW) return false;
     if (p.border_h < 6 || p.border_w < 6) return false;    // every window of a cropped pixel is inside the image
@@ -546,13 +553,11 @@ bool volume_fast_supported(const msnet_volume_params& p, int Hb, int Wb, int nd)
     if (Wb + 8 > 2500) return false;                        // LDS band of the Sobel-SAD kernel (16 rows x (Wb + 8) floats)
     if (cdiv(Hb - 2 * p.border_h, kBandRMin) > kMaxBands) return false;   // band table of the Sobel-SAD kernels
     if (Hb > 8000) return false;                            // exact vertical sums: Hb * 2040 < 2^24 (sadsob_bandsum_kernel)
+    // slot 0 of sadsob_bandsum_kernel sums the border_h - 3 image rows above band 0 with at most R terms (R = 11 for the wide
+    // images that need 16-row bands, else 27): a taller top border takes the generic path
+    const bool wide = (size_t)(27 + kSW) * band_ls(Wb) * sizeof(float) > 160 * 1024;
+    if (p.border_h - kSW / 2 - 1 > (wide ? 11 : 27)) return false;
     return true;
-}
-
-static int band_ls(int Wb) {
-    int LS = Wb + 1;
-    while (LS % 8 != 4) ++LS;
-    return LS;
 }
 
 // bytes of workspace the fast path uses: census bits, NCC tables, four float images, Sobel-SAD checkpoints
@@ -564,23 +569,38 @@ size_t volume_fast_workspace_bytes(int Hb, int Wb, int nd) {
 
 // Second stream of the build: the Sobel-SAD kernels (one wave per workgroup busy most of the time, LDS-capacity-bound) run
 // beside the feature kernel of the other three matchers (VALU- and store-bound) instead of in front of it.  One helper
-// stream and two events per device, created on first use; fork / join are ordinary event waits, so the build stays
-// asynchronous on the caller's stream and capturable.
-struct VolAux { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false, tried = false; };
-static VolAux& vol_aux() {
-    static VolAux aux[32];
+// stream and two events per (device, caller stream), created on first use: builds issued on DIFFERENT streams (two host
+// threads, two VolumeBuilders) never share an event; builds on one stream are ordered by that stream.  fork / join are
+// ordinary event waits, so the build stays asynchronous on the caller's stream and capturable.
+struct VolAux { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
+static VolAux& vol_aux(hipStream_t caller) {
+    static std::map<std::pair<int, hipStream_t>, VolAux*> aux;
     static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) dev = 0;
-    VolAux& x = aux[dev];
-    if (!x.tried) {
-        x.tried = true;
-        x.ok = hipStreamCreateWithFlags(&x.s, hipStreamNonBlocking) == hipSuccess &&
-               hipEventCreateWithFlags(&x.fork, hipEventDisableTiming) == hipSuccess &&
-               hipEventCreateWithFlags(&x.join, hipEventDisableTiming) == hipSuccess;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    VolAux*& x = aux[std::make_pair(dev, caller)];
+    if (!x) {
+        x = new VolAux();
+        x->ok = hipStreamCreateWithFlags(&x->s, hipStreamNonBlocking) == hipSuccess &&
+                hipEventCreateWithFlags(&x->fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&x->join, hipEventDisableTiming) == hipSuccess;
     }
-    return x;
+    return *x;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: set once per (device, kernel), under a lock
+template <class K>
+static void allow_big_lds(K kernel) {
+    static std::mutex mu;
+    static unsigned long long done = 0;                     // bit = device ordinal (this static exists once per kernel type)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); return; }
+    std::lock_guard<std::mutex> lk(mu);
+    if (!(done >> dev & 1ull)) {
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        done |= 1ull << dev;
+    }
 }
 
 int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int nd, const msnet_volume_params& p, void* workspace,
@@ -600,10 +620,15 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
     a.Hc = Hb - 2 * p.border_h; a.Wc = Wb - 2 * p.border_w;
     const size_t plane = (size_t)a.Hc * a.Wc;
     const dim3 gpix(cdiv(a.Wc, 64), cdiv(a.Hc, 4), 1);
-    static const int band_skip = [] { const char* e = getenv("MSNET_BAND_SKIP"); return e ? atoi(e) : 0; }();     // diagnostic: skip phases
-    static const int band_cfg = [] { const char* e = getenv("MSNET_BAND_CFG"); return e ? atoi(e) : 0; }();       // tuning: band height / threads
+#ifdef EXP_VOLUME_KNOBS      // diagnostic builds only: the shipped library takes nothing from the environment here
+    static const int band_skip = [] { const char* e = getenv("MSNET_BAND_SKIP"); return e ? atoi(e) : 0; }();     // skip phases (wrong results)
+    static const int band_cfg = [] { const char* e = getenv("MSNET_BAND_CFG"); return e ? atoi(e) : 0; }();       // band height / threads
     static const bool want_overlap = [] { const char* e = getenv("MSNET_VOL_STREAMS"); return !(e && e[0] == '0'); }();
-    VolAux& aux = vol_aux();
+#else
+    constexpr int band_skip = 0, band_cfg = 0;
+    constexpr bool want_overlap = true;
+#endif
+    VolAux& aux = vol_aux(s);
     const bool overlap = want_overlap && aux.ok;
     hipStream_t sb = overlap ? aux.s : s;                  // stream of the Sobel-SAD kernels
 
@@ -626,11 +651,7 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
             if (nbands > kMaxBands) return fail("msnet_build_volume: %d Sobel-SAD bands (max %d)", nbands, kMaxBands);
             const size_t lds = (size_t)(R + kSW) * LS * sizeof(float);
             if (lds > 160 * 1024) return fail("msnet_build_volume: image width %d too large for the Sobel-SAD band", Wb);
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void*)sadsob_band_kernel<R, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                attr_set = true;
-            }
+            if (lds > 64 * 1024) allow_big_lds(sadsob_band_kernel<R, NT>);
             hipLaunchKernelGGL(sadsob_bandsum_kernel<R>, dim3(cdiv(LS, 256), nbands, nd), dim3(256), 0, sb, a, ck, LS, nbands);
             hipLaunchKernelGGL((sadsob_band_kernel<R, NT>), dim3(nd * nbands), dim3(NT), lds, sb, a, ck, park, LS, nbands, band_skip);
             return 0;
