@@ -447,7 +447,9 @@ def test_cfg3_psmnet_full_size(gpu):
       G1  the 28-conv trunk: logits cost3 (pre-trilinear, psmnet_3dcnn.py:147) vs the fp32 oracle, relative error <= 1e-5
           (the golden taps use 1e-4; fp32-vs-fp64 of the oracle itself is 9e-7 here);
       G2  the tail alone: HIP trilinear+softmax+regression vs torch's fp32 tail ON THE SAME (HIP) LOGITS;
-      G3  end to end vs the fp32 oracle, per pixel: |disp - oracle| <= 1e-3 + kappa_i * (max|delta logits| + eps_tail).
+      G3  end to end vs the fp32 oracle, per pixel: |disp - oracle| <= 1e-3 + kappa_i * (1e-5 * max|logit| + eps_tail) -- the
+          G1 BOUND, not the measured logit error -- and >= 95 % of the map within a flat 1e-3.
+          (tests/test_gpu_fullsize_golden.py repeats this against the REFERENCE's own map with a 5e-6 bound.)
 
     Why not a flat 1e-3 end to end: with these random-init weights the softmax over D=192 is broad (kappa up to ~80
     disparities per unit logit), so the oracle's own fp32 tail differs from an fp64 tail ON IDENTICAL LOGITS by 2e-2, and
@@ -485,15 +487,18 @@ def test_cfg3_psmnet_full_size(gpu):
     assert float((got.double() - t64).abs().max()) <= float(noise32.max()) + DISP_TOL   # no further from exact than torch's fp32 tail
     # G3
     err = (got - ref).abs()
-    tol = DISP_TOL + kappa * (dl + eps_tail)
+    G1_BOUND = 1e-5                                              # the G1 gate itself: the tolerance must not follow the measured error
+    dl_bound = G1_BOUND * float(c3_ref.abs().max())
+    tol = DISP_TOL + kappa * (dl_bound + eps_tail)
     tight = float((tol <= 2 * DISP_TOL).float().mean())
-    print("psmnet full size: max|disp - oracle| = %.3e; per-pixel tolerance 1e-3 + kappa*(%.2e): %.1f%% of pixels gated at "
-          "<= 2e-3, worst err/tol %.3f; pixels with |torch-fp32 - fp64 tail| <= 1e-4: %.1f%%"
-          % (float(err.max()), dl + eps_tail, 100 * tight, float((err / tol).max()), 100 * float((noise32 <= 1e-4).float().mean())))
+    print("psmnet full size: max|disp - oracle| = %.3e; per-pixel tolerance 1e-3 + kappa*(%.2e) [from the G1 bound, measured dl %.2e]: "
+          "%.1f%% of pixels gated at <= 2e-3, worst err/tol %.3f; pixels with |torch-fp32 - fp64 tail| <= 1e-4: %.1f%%"
+          % (float(err.max()), dl_bound + eps_tail, dl, 100 * tight, float((err / tol).max()), 100 * float((noise32 <= 1e-4).float().mean())))
     assert got.shape == ref.shape == (1, 544, 960)
     assert float(got.min()) >= 0 and float(got.max()) <= maxdisp - 1
     assert float((err - tol).max()) <= 0
-    assert tight >= 0.25                                         # the gate is not vacuous
+    assert tight >= 0.10                                         # the gate is not vacuous (bound-based tolerance: fewer pixels sit at <= 2e-3)
+    assert float((err <= DISP_TOL).float().mean()) >= 0.95        # and the map as a whole is within the flat gate
 
 
 def test_gcnet_16_plane_volume(gpu):
@@ -672,7 +677,7 @@ def test_split_fp16_small_magnitudes(gpu, ci, co, stride, transposed, xs, ws):
         y = hipops.deconv3d_k3s2(_cl(x), plan.wpk, plan.scale, plan.shift, co, relu=True, f16s=True)
     else:
         y = hipops.conv3d_k3(_cl(x), plan.wpk, plan.scale, plan.shift, co, stride=stride, relu=True, f16s=True)
-    err = _rel(_nc(y).double(), ref)
+    err = float((_nc(y).double() - ref).abs().max() / ref.abs().max())        # (relative to the true magnitude, however small)
     print("split-fp16 small magnitudes %d->%d s%d%s x*%.0e w*%.0e: rel err %.2e (max|ref| %.2e)"
           % (ci, co, stride, " T" if transposed else "", xs, ws, err, float(ref.abs().max())))
     assert float(ref.abs().max()) > 0
