@@ -136,3 +136,45 @@ def test_cfg5_kitti_shape(gpu):
     assert torch.equal(two[0], disp[0].cuda())
     assert torch.equal(two[1], model(vol.flip(-1).contiguous().unsqueeze(0))[0])
     assert driver_utils.crop_disparity(disp.numpy(), 384, 1248, 375, 1242).shape == (375, 1242)
+
+
+def test_cfg1_plumbing_shape(gpu):
+    """Config #1 (BASELINE.json configs[0], the reference's own CPU-runnable case): 256x512, D=64 -> bordered 148x276 images,
+    volume [8,32,128,256], disparity [256,512]; end to end vs the oracle."""
+    from msnets_amd import cbmv_generator as cg
+    model, sd = _model(64)
+    left, right, vol_ref, disp_ref = _oracle_e2e(128, 256, 32, 7, sd)
+    assert left.shape == (148, 276)
+    vol = cg.build_ms_volume(torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda(), 32)
+    _check_volume(vol.cpu().numpy(), vol_ref, "cfg1")
+    disp = model.cuda()(vol.unsqueeze(0)).cpu()
+    assert disp.shape == disp_ref.shape == (1, 256, 512)
+    err = float((disp - disp_ref).abs().max())
+    print("cfg1 end to end: max|disp - oracle| = %.3e" % err)
+    assert err <= DISP_TOL
+
+
+def test_power_of_two_scaling_is_exact_at_full_size(gpu):
+    """A size-independent property of the split-fp16 conv at the full benchmark shape (no oracle needed): with zero shift,
+    scaling the input by a power of two scales the output by exactly that power of two -- hi = fp16(x) and
+    lo = fp16((x - hi) * 2^11) both scale exactly while nothing leaves the fp16 normal range, and fp32 accumulation of exactly
+    scaled terms is exactly scaled.  Checked bit for bit on conv3dbn_2's shape (32->32, 96x272x480, sliding-window kernel), on
+    the stride-2 32->64 layer and on the 64->32 transposed layer."""
+    from msnets_amd import hipops
+    g = torch.Generator().manual_seed(5)
+    for kind, ci, co, stride, dims in (("conv", 32, 32, 1, (96, 272, 480)), ("conv", 32, 64, 2, (96, 272, 480)),
+                                       ("deconv", 64, 32, 2, (48, 136, 240))):
+        d, h, w = dims
+        x = torch.rand((1, d, h, w, ci), generator=g).cuda()
+        if kind == "conv":
+            wt = (torch.randn((co, ci, 3, 3, 3), generator=g) * 0.05).cuda()
+            wpk = hipops.pack_conv_weight(wt, f16s=True, stride=stride)
+            f = lambda t: hipops.conv3d_k3(t, wpk, None, None, co, stride=stride, relu=True, f16s=True)     # noqa: E731
+        else:
+            wt = (torch.randn((ci, co, 3, 3, 3), generator=g) * 0.05).cuda()
+            wpk = hipops.pack_conv_weight(wt, transposed=True, f16s=True)
+            f = lambda t: hipops.deconv3d_k3s2(t, wpk, None, None, co, relu=True, f16s=True)               # noqa: E731
+        y1 = f(x).clone()
+        for k in (2.0, 8.0, 64.0):        # (downwards the property ends where hi = fp16(x) turns subnormal: torch.rand has such values)
+            assert torch.equal(f(x * k), y1 * k), (kind, ci, co, stride, k)
+        assert float(y1.abs().max()) > 0
