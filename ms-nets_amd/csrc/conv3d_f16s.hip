@@ -890,13 +890,15 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #endif
     [[maybe_unused]] int sidx = 0;
     TileCtr ctr = ctr0;
-    // Start stagger: identical persistent workgroups run in lockstep, so all 256 CUs reach their epilogues together and the
-    // 64 KB store bursts of a Co = 64 tile queue on HBM (5.2 K cycles per tile in the per-wave stamps, ~1.2 K when a CU stores
-    // alone).  Delaying the workgroups of phase blockIdx & 3 by phase * stagger spreads the bursts; the loader waves wait at b1.
+#ifdef EXP_STAGGER
+    // Experiment (measured +-1 %): identical persistent workgroups run in lockstep, so all 256 CUs reach their
+    // epilogues together and the 64 KB store bursts of a Co = 64 tile queue on HBM (5.2 K cycles per tile in the per-wave
+    // stamps).  Delaying the workgroups of phase blockIdx & 3 by phase * stagger spreads the bursts; the loaders wait at b1.
     if (a.stagger) {
         const int nsl = (int)(blockIdx.x & 3u) * a.stagger;
         for (int q = 0; q < nsl; ++q) __builtin_amdgcn_s_sleep(16);
     }
+#endif
     for (int it = 0; it < nitems; ++it) {
         int n, od0, oh0, ow0, chunk, cg;
         coords(ctr, n, od0, oh0, ow0, chunk, cg);

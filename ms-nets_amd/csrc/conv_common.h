@@ -32,7 +32,7 @@ struct ConvArgs {
     int nbtot;             // Co / 32
     int nseg, seglen;      // sliding-window kernels: depth segments per tile column, tiles (depth steps) per segment
     unsigned* oflag;       // device word that receives 1 when an output leaves the fp16 range (msnet_set_overflow_flag), or null
-    int stagger;           // start delay per workgroup phase (blockIdx & 3), in units of 1024 cycles; 0 = none (see launch_f16s)
+    int stagger;           // -DEXP_STAGGER builds only: start delay per workgroup phase (blockIdx & 3) in units of 1024 cycles
 };
 
 // Range guard of the split-fp16 kernels (conv3d_f16s.hip: every operand's `hi` half is an fp16): an activation of magnitude
