@@ -204,7 +204,13 @@ def self_launch(n):
     argv = [a for a in sys.argv[1:] if a != "--self-launch"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
-    return subprocess.call(cmd, env=env)
+    # rank 0's JSON line goes to stdout alone; anything else the ranks or RCCL print on stdout (RCCL's version banner) is relayed
+    # on stderr, so that `python bench.py --gpus N` prints ONE line on stdout as the single-process run does
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in proc.stdout:
+        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
+        sys.stdout.flush()
+    return proc.wait()
 
 
 def main():

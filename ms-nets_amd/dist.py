@@ -24,6 +24,7 @@ def init_from_env(backend=None):
     if torch.cuda.is_available():
         torch.cuda.set_device(local)
     if not dist.is_initialized():
+        os.environ.setdefault("NCCL_DEBUG", "WARN")      # no RCCL version banner on stdout next to a caller's own output
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)

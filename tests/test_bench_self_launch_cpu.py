@@ -27,4 +27,4 @@ def test_bench_parent_makes_no_gpu_call_before_launching():
     main = src[src.index("def main():"):]
     assert main.index("self_launch(args.gpus)") < main.index("import msnets_amd")
     body = src[src.index("def self_launch"):src.index("def main():")]
-    assert "os.exec" not in body and "subprocess.call" in body
+    assert "os.exec" not in body and "subprocess.Popen" in body

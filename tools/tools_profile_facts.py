@@ -50,7 +50,9 @@ if dom:
     for k, v in clk.items():
         if k == dom["Name"]:
             out["sustained_clock_ghz"]["conv3d_s1_f16s_co32"] = sum(v) / len(v)
+avg_ns = {r["Name"]: float(r["AverageNs"]) for r in rows}
 for k, v in clk.items():
-    if "msnet" in k:
+    # (GRBM_GUI_ACTIVE / 8 / duration is only meaningful for launches long enough to keep all eight XCDs busy throughout)
+    if "msnet" in k and avg_ns.get(k, 0.0) >= 2.0e5:
         out["sustained_clock_ghz"].setdefault(k.replace("msnet::", "")[:100], sum(v) / len(v))
 print(json.dumps(out, indent=1))
