@@ -46,6 +46,11 @@ __device__ __forceinline__ void static_for(F&& f) {
 #ifndef S2_LOADER_WAVES
 #define S2_LOADER_WAVES 8
 #endif
+#ifdef EXP_S2_PADDED
+#define S2_SWZ false            // experiment: the round-2 stride-2 layout (padded 80-byte records, two weight buffers)
+#else
+#define S2_SWZ true
+#endif
 #ifndef MSNET_A_AUX
 #define MSNET_A_AUX 0           // cache-policy bits of the loaders' tile requests (2 = nt, measured: see DESIGN.md 4.1d)
 #endif
@@ -195,7 +200,12 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     constexpr int ID = (TD - 1) * STRIDE + 3, IH = (TH - 1) * STRIDE + 3, IW = (TW - 1) * STRIDE + 3;
     constexpr int HB = 2 * CC;                          // bytes of the hi (or lo) half of a voxel record
     constexpr int RB = SWZ ? 2 * HB : 2 * HB + 16;      // bytes per voxel record in LDS (hi + lo [+ 16 pad])
-    static_assert(!SWZ || KS == 2, "the swizzle is written for 128-byte records");
+    // S2SWZ (stride 2, 16-channel chunks): 64-byte records [hi 32 B | lo 32 B] whose four 16-byte slots are XORed with
+    // (record column >> 2) & 3 -- lanes of a ds_read_b128 group whose records share a bank base (every fourth record) then read
+    // different slots, for any tap offset.  26 KB less LDS than the padded 80-byte records, which is what makes room for the
+    // third weight buffer (B3) on the stride-2 kernel.
+    constexpr bool S2SWZ = SWZ && STRIDE == 2 && KS == 1;
+    static_assert(!SWZ || KS == 2 || S2SWZ, "the swizzle is written for 128-byte records (and 64-byte records at stride 2)");
     // M-blocks of 32 consecutive voxels read conflict-free; BW = 16 (two 16-voxel rows) leaves one of the four
     // ds_read_b128 lane groups 2-way conflicted on 4 lanes with the 128-byte swizzle -- accepted for the 16-mod-32 widths.
     static_assert(BW == 32 || (BW == 16 && SWZ), "M-block shapes the LDS layouts were checked for");
@@ -210,7 +220,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     // Weight-group buffers in LDS.  B3 (three buffers, where they fit: the Co = 32 stride-1 kernels): group g+2 is copied while
     // group g is multiplied, so group g+1 has been in LDS since barrier g_(g-1) and its first B fragments are read BEFORE
     // barrier g_g, like the A fragments -- with two buffers every group started with an exposed LDS round trip behind its barrier.
-    constexpr bool B3 = !RESB && STRIDE == 1 && NB == 1 && NPOS * RB + 3 * GB <= 160 * 1024;
+    constexpr bool B3 = !RESB && ((STRIDE == 1 && NB == 1) || S2SWZ) && NPOS * RB + 3 * GB <= 160 * 1024;
     // KHS (the Co = 32 kernels: 1x32-voxel M-blocks, a wave's two M-blocks are adjacent h rows): weight groups are (kd, kw)
     // COLUMNS of the 3x3x3 stencil instead of (kd, kh) rows.  M-block 0 at tap row kh+1 reads the LDS row M-block 1 reads at kh,
     // so a 16-channel step loads four A rows once (8 ds_read_b128) and uses them for 3 kh x 2 M-blocks: 28 fragment reads per
@@ -293,13 +303,13 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         // Swizzled records: the 16-byte slot is XORed with (iw >> 1) & 7, iw = the voxel's COLUMN in the tile.  (Keying on the
         // linear voxel index instead made the two 16-voxel rows of a 2x16 M-block -- 18 voxels apart -- collide on two of the
         // 16 slots in every ds_read_b128 lane group: 31 % of the LDS cycles of the 2x8x16 kernel were conflict cycles.)
-        static_assert(!SWZ || (IW % 2 == 0), "an even row pitch keeps record parity = column parity");
+        static_assert(!SWZ || S2SWZ || (IW % 2 == 0), "an even row pitch keeps record parity = column parity");
         const int lhi0 = (lt / VR) * RB + ((lt % VR) & 1) * 8 + (((lt % VR) >> 1) << 4);   // hi half of slot u = 0 in plane slot 0 (padded records)
         // Stride 2: a lane's voxels are two columns apart, and with 16-byte-aligned records any padded layout then puts 16
         // lanes on 8 distinct bank slots (2-way conflict on every A read: 27 % of the kernel's LDS cycles).  The columns of a
         // tile row are therefore stored de-interleaved -- even columns first, then the odd ones -- so that a tap reads
         // consecutive records again (tap kw: parity kw & 1, start kw >> 1).
-        constexpr bool CPERM = STRIDE == 2 && !SWZ;
+        constexpr bool CPERM = STRIDE == 2;
         constexpr int CHALF = (IW + 1) / 2;
         int lsw_[(SWZ || CPERM) ? PL : 1];              // in-plane LDS offset of slot u (swizzle / column permutation included)
         if constexpr (SWZ || CPERM) {
@@ -307,8 +317,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             for (int u = 0; u < PL; ++u) {
                 const int slot = u * LT + lt, pos = slot / VR, c4 = slot % VR;
                 const int ih = pos / IW, iw = pos % IW;
-                const int key = SWZ ? ((iw >> 1) & 7) : 0;
                 const int col = CPERM ? (iw & 1) * CHALF + (iw >> 1) : iw;
+                const int key = S2SWZ ? ((col >> 2) & 3) : SWZ ? ((iw >> 1) & 7) : 0;
                 lsw_[u] = (ih * IW + col) * RB + (c4 & 1) * 8 + (((c4 >> 1) ^ key) << 4);
             }
         }
@@ -401,7 +411,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #endif
                     const int off = pslot * (IH * IW * RB) + ((SWZ || CPERM) ? lsw_[u] : lhi0 + u * (LT / VR) * RB);
                     *reinterpret_cast<half4*>(lds + off) = hi;
-                    *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ 64) : off + HB)) = lo;
+                    *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ HB) : off + HB)) = lo;
                 }
             }
         };
@@ -714,8 +724,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         const int lh = bh * BH + r / BW, lw = bw_ * BW + r % BW;
         // SLIDE: the plane comes from grp_off.  Stride 2 with de-interleaved columns: output column lw reads record lw of
         // the even half (kw = 0, 2) or of the odd half (kw = 1), see tap_col below.
-        vox0[i] = ((SLIDE ? 0 : bd * STRIDE * IH) + lh * STRIDE) * IW + ((STRIDE == 2 && !SWZ) ? lw : lw * STRIDE);
-        lwv[i] = lw * STRIDE;                           // tile column of the lane's voxel at kw = 0 (swizzle key)
+        vox0[i] = ((SLIDE ? 0 : bd * STRIDE * IH) + lh * STRIDE) * IW + lw;      // (stride 2: de-interleaved columns, record lw)
+        lwv[i] = lw;                                    // record column of the lane's voxel at kw = 0 (swizzle key)
     }
     int rot = 0;                                        // SLIDE: plane-slot rotation of the current item
     // voxel offset of group g's (kd, kh) row for M-block i
@@ -1020,7 +1030,13 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #pragma unroll
             for (int i = 0; i < MB; ++i) {
                 const int goff = goffs[i];
-                if (SWZ) {
+                if constexpr (S2SWZ) {
+                    constexpr int CH = (IW + 1) / 2;
+                    const int tcol = (t & 1) * CH + (t >> 1);                            // record offset of tap kw = t
+                    const int off = (vox0[i] + goff + tcol) * RB + ((hh ^ (((lwv[i] + tcol) >> 2) & 3)) << 4);
+                    ah[slot][i] = *reinterpret_cast<const half8*>(lds + off);
+                    al[slot][i] = *reinterpret_cast<const half8*>(lds + (off ^ HB));
+                } else if (SWZ) {
                     const int vox = vox0[i] + goff + t;
                     const int off = vox * RB + (((ks * 2 + hh) ^ (((lwv[i] + t) >> 1) & 7)) << 4);
                     ah[slot][i] = *reinterpret_cast<const half8*>(lds + off);
@@ -1151,6 +1167,11 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #pragma unroll
             for (int i = 0; i < MB; ++i) plw[i] = 0;
         } else {
+#ifdef EXP_S2_UNROLL
+            if constexpr (STRIDE == 2) {
+                static_for<9>([&](auto gc) { do_group(decltype(gc)::value, [](auto) {}); });
+            } else
+#endif
 #pragma unroll 1                                 // (expanding the nine groups here too was measured: Co=64 spills, stride 2 gains 1 %)
             for (int g = 0; g < 9; ++g) do_group(g, [](auto) {});
         }
@@ -2086,8 +2107,8 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
             return launch_direct_f16s<false>(stride == 2 ? "conv3d_s2_f16s" : (Co == 32 ? "conv3d_s1_f16s_co32" : "conv3d_s1_f16s_co64"),
                                              a, stride, stride == 2 ? 1 : 2, Co == 32 ? 1 : 2, s);
     }
-    if (stride == 2)   // 2x2x32 output tile <- 5x5x65 input voxels x 16 channels (130 KB); 4 M-blocks, one per MFMA wave
-        return launch_f16s<2, 2, 32, 32, 1, 2, false, 1, false, 2, S2_LOADER_WAVES>("conv3d_s2_f16s", a, s);
+    if (stride == 2)   // 2x2x32 output tile <- 5x5x65 input voxels x 16 channels (104 KB of 64-byte swizzled records); 4 M-blocks, one per MFMA wave
+        return launch_f16s<2, 2, 32, 32, 1, 2, S2_SWZ, 1, false, 2, S2_LOADER_WAVES>("conv3d_s2_f16s", a, s);
     //                                    TD TH TW  BW MB NB
     if (Ci == 8) {
         if (Co == 64) return launch_c8_f16s<2>("conv3d_s1_c8_f16s", a, s);
