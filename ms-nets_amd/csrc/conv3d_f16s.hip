@@ -1069,7 +1069,13 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         const u32x4* const wcur = wbase_of(it);
         const u32x4* const wnxt = wbase_of(it + 1);
 #endif
-        auto do_group = [&](int g, auto drain) {
+        // FIRST / LAST (compile-time: is this group 0 / group 8 of the item): the rolled loop over groups 1..7 then has NO
+        // run-time condition around its fragment prefetches.  With `if (g < 8)` / `if (g == 0)` inside one rolled body the
+        // compiler's waitcnt pass had to assume the path WITHOUT the next group's prefetch burst, so the last step of every group
+        // waited with lgkmcnt(4) .. lgkmcnt(0) -- i.e. for the 12 reads just issued for the NEXT group -- and every group paid an
+        // LDS round trip (~450 of ~1050 cycles per 18-MFMA group of the stride-2 kernel in the per-wave stamps).
+        auto do_group = [&](int g, auto firstc, auto lastc, auto drain) {
+            constexpr bool FIRST = decltype(firstc)::value, LAST = decltype(lastc)::value;
             const int g3 = g - 3 * ((g * 11) >> 5);     // g % 3 (g < 9)
             const unsigned char* bb = lds_b + (RESB ? g : (B3 ? g3 : ((gg0 + g) & 1))) * GB + lane * 16;
 #ifdef EXP_B_EARLY
@@ -1087,7 +1093,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             const u32x4* const bgn = g < 8 ? bg + PG : wnxt;
             (void)bb;
 #else
-            if (!BEARLY || g == 0) {                    // (B3: the previous group read these before its barrier)
+            if (!BEARLY || FIRST) {                     // (B3: the previous group read these before its barrier)
 #pragma unroll
                 for (int q = 0; q < PF; ++q) frag_b(q, q, bb);
             }
@@ -1097,12 +1103,12 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #ifndef EXP_NO_FRAG
 #ifdef EXP_BGLOB
                 if (s + PF < NS) frag_a(s + PF, (s + PF) % R, goff);
-                else if (g < 8) frag_a(s + PF - NS, (s + PF) % R, goff_next);
+                else if (!LAST) frag_a(s + PF - NS, (s + PF) % R, goff_next);
                 if (s + PFB < NS) frag_bg(s + PFB, (s + PFB) % BR, bg);
                 else frag_bg(s + PFB - NS, (s + PFB) % BR, bgn);
 #else
                 if (s + PF < NS) { frag_a(s + PF, (s + PF) % R, goff); frag_b(s + PF, (s + PF) % R, bb); }
-                else if (g < 8) {
+                else if constexpr (!LAST) {
                     frag_a(s + PF - NS, (s + PF) % R, goff_next);
                     if constexpr (BEARLY) frag_b(s + PF - NS, (s + PF) % R, bb_next);
                 }
@@ -1149,9 +1155,17 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 __builtin_amdgcn_sched_barrier(0);
             });
 #ifndef EXP_NO_GROUP_BARRIER
-            if (!RESB && g < 8) {
+            if constexpr (!RESB && !LAST) {
+                // g_g.  The reads in flight here are fragment prefetches for group g+1: A fragments of tile planes that are still
+                // live (the loaders overwrite a plane only after the barrier that ends its LAST group, and group g+1 never reads a
+                // plane that dies at g_g), and -- three buffers -- B fragments of buffer g+1, which is next written two barriers
+                // later.  The buffer the loaders refill after g_g (group g's) was consumed by this group's MFMAs.  So no drain.
                 STAMP(wave, sidx, lane);
-                MSNET_LDS_BARRIER();                    // g_g
+#ifdef EXP_FULL_GROUP_BARRIER
+                MSNET_LDS_BARRIER();
+#else
+                MSNET_READER_BARRIER();
+#endif
                 STAMP(wave, sidx, lane);
             }
 #endif
@@ -1159,7 +1173,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         if constexpr (DRAIN) {
             static_for<9>([&](auto gc) {
                 constexpr int g = decltype(gc)::value;
-                do_group(g, [&](auto sc_) { drain_piece(std::integral_constant<int, g * NS + decltype(sc_)::value>{}); });
+                do_group(g, std::integral_constant<bool, g == 0>{}, std::integral_constant<bool, g == 8>{},
+                         [&](auto sc_) { drain_piece(std::integral_constant<int, g * NS + decltype(sc_)::value>{}); });
             });
             if (pend_live) flag_overflow(a.oflag, pamax);
             pamax = 0.f;
@@ -1167,13 +1182,12 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #pragma unroll
             for (int i = 0; i < MB; ++i) plw[i] = 0;
         } else {
-#ifdef EXP_S2_UNROLL
-            if constexpr (STRIDE == 2) {
-                static_for<9>([&](auto gc) { do_group(decltype(gc)::value, [](auto) {}); });
-            } else
-#endif
-#pragma unroll 1                                 // (expanding the nine groups here too was measured: Co=64 spills, stride 2 gains 1 %)
-            for (int g = 0; g < 9; ++g) do_group(g, [](auto) {});
+            using T_ = std::integral_constant<bool, true>;
+            using F_ = std::integral_constant<bool, false>;
+            do_group(0, T_{}, F_{}, [](auto) {});
+#pragma unroll 1                                 // (expanding all nine groups was measured: Co=64 spills, stride 2 +-0)
+            for (int g = 1; g < 8; ++g) do_group(g, F_{}, F_{}, [](auto) {});
+            do_group(8, F_{}, T_{}, [](auto) {});
         }
         }
         if (chunk == nchunks - 1) { pending = true; pn = n; pod0 = od0; poh0 = oh0; pow0 = ow0; pcg = cg; }

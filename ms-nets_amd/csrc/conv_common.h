@@ -227,4 +227,16 @@ __device__ __forceinline__ void epilogue_store_split(const f32x16& acc, const f3
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");  \
     } while (0)
 
+// Barrier for a wave that only READS LDS between two barriers (the MFMA waves at a weight-group barrier): no release fence,
+// i.e. no s_waitcnt lgkmcnt(0) -- its fragment prefetches stay in flight across the barrier.  Safe where nothing another wave
+// writes after this barrier can be the target of a read this wave issued before it (the callers state why); the partner waves
+// publish their LDS writes with the full MSNET_LDS_BARRIER.  The memory clobber keeps the compiler from moving LDS accesses
+// across it; the wave itself executes in order.
+#define MSNET_READER_BARRIER()                                           \
+    do {                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        asm volatile("s_barrier" ::: "memory");                          \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    } while (0)
+
 }  // namespace msnet
