@@ -999,8 +999,14 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 });
 #ifndef EXP_NO_GROUP_BARRIER
                 if constexpr (g < 8) {
+                    // g_g: in flight are the A rows and B fragments of group g+1's first steps -- live tile planes and the weight
+                    // buffer published at g_(g-1), neither of which a loader writes before g_(g+1): no drain (see do_group)
                     STAMP(wave, sidx, lane);
-                    MSNET_LDS_BARRIER();                // g_g
+#ifdef EXP_FULL_GROUP_BARRIER
+                    MSNET_LDS_BARRIER();
+#else
+                    MSNET_READER_BARRIER();
+#endif
                     STAMP(wave, sidx, lane);
                 }
 #endif
