@@ -169,6 +169,17 @@ int msnet_deconv3d_k3s2_f16s(const float* x, const void* wpk_f16s, const float* 
 int msnet_deconv3d_k3s2(const float* x, const float* wpk, const float* scale, const float* shift,
                         const float* residual, float* y, int N, int D, int H, int W, int Ci, int Co,
                         int relu, msnet_stream_t stream);
+/* Winograd F(2,3) along depth for the 32 -> 32 stride-1 convbn_3d layers (gcnet_3dcnn.py:101 conv3dbn_2; psmnet_3dcnn.py:94-101
+ * dres0 / dres1 and the hourglass 32 -> 32 layers): two thirds of the MFMAs of msnet_conv3d_k3_f16s for the same result
+ * (F(2,3) is exact in real arithmetic; with 22-bit split operands a layer stays within 5e-6 of the fp64 conv).
+ * g36: f32 [32][32][36], the transformed BN-folded weights -- tap T = k*9 + kh*3 + kw, g0 = w[kd=0], g1 = (w0+w1+w2)/2,
+ * g2 = (w0-w1+w2)/2, g3 = w[kd=2] (the caller computes them in fp64); packed: 36*32*32*2 fp16 = 73,728 bytes.
+ * _supported: 1 when the shape is taken (stride 1, 32 -> 32, not a small layer). */
+int msnet_pack_conv_weight_wd_f16s(const float* g36, void* packed, msnet_stream_t stream);
+int msnet_conv3d_k3_wd_f16s_supported(int D, int H, int W, int Ci, int Co, int stride);
+int msnet_conv3d_k3_wd_f16s(const float* x, const void* wpk_wd, const float* scale, const float* shift,
+                            const float* residual, float* y, int N, int D, int H, int W, int relu,
+                            msnet_stream_t stream);
 /* The first layer (cbmv_in_planes = 8, gcnet_3dcnn.py:99-101) read straight from the module's NCDHW volume
  * x: f32[N][8][D][H][W] (the layout cbmv_generator.py:307-308 produces) -> y: NDHWC f32[N][D][H][W][Co], Co = 32 or 64, stride 1,
  * no residual; split-fp16 MFMA.  Replaces msnet_ncdhw_to_ndhwc + msnet_conv3d_k3_f16s for that layer: the volume is not

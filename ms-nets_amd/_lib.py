@@ -60,6 +60,9 @@ SIGNATURES = {
     "msnet_pack_deconv_weight_f16s": (c_int, [P, P, c_int, c_int, P]),
     "msnet_deconv3d_k3s2_f16s": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_deconv3d_k3s2": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "msnet_pack_conv_weight_wd_f16s": (c_int, [P, P, P]),
+    "msnet_conv3d_k3_wd_f16s_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
+    "msnet_conv3d_k3_wd_f16s": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_conv3d_k3_c8_ncdhw_f16s": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_conv3d_k3_cout1": (c_int, [P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_softargmin": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),

@@ -140,7 +140,7 @@ class GCNet_CostVolumeAggre(nn.Module):
         def conv(x, name, stride=1, residual=None):
             p = pl[name]
             return hipops.conv3d_k3(x, p.wpk, p.scale, p.shift, p.co, stride=stride, relu=True, residual=residual,
-                                     f16s=p.f16s)
+                                     f16s=p.f16s, wpk_wd=p.wpk_wd)
 
         def block(x, name, stride):
             x = conv(x, name + ".convbn_3d_1", stride)

@@ -125,9 +125,45 @@ def get_default_precision():
     return _default_precision
 
 
-def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16s=False):
+USE_WINOGRAD_DEPTH = True      # 32 -> 32 stride-1 layers on the Winograd-depth kernel where the shape is taken (A/B switch)
+
+
+def winograd_depth_weights(w):
+    """w f32 [32,32,3,3,3] (BN-folded, pre-scaled) -> packed image of msnet_conv3d_k3_wd_f16s.  The F(2,3) transform of the
+    three depth taps is done in fp64 on the host: g0 = w[kd=0], g1 = (w0+w1+w2)/2, g2 = (w0-w1+w2)/2, g3 = w[kd=2]."""
+    w = require_gpu_f32(w, "weight")
+    if tuple(w.shape) != (32, 32, 3, 3, 3):
+        raise ValueError("winograd_depth_weights takes a [32,32,3,3,3] weight (got %s)" % (tuple(w.shape),))
+    wd = w.double()
+    w0, w1, w2 = wd[:, :, 0], wd[:, :, 1], wd[:, :, 2]                      # [Co,Ci,3,3] each
+    g = torch.stack([w0, (w0 + w1 + w2) * 0.5, (w0 - w1 + w2) * 0.5, w2], dim=2)      # [Co,Ci,4,3,3]
+    g36 = g.reshape(32, 32, 36).float().contiguous()
+    out = torch.empty(36 * 32 * 32, device=w.device, dtype=torch.float32)             # 2 fp16 per weight = one float each
+    check(_lib.load().msnet_pack_conv_weight_wd_f16s(ptr(g36), ptr(out), stream_ptr()), "msnet_pack_conv_weight_wd_f16s")
+    return out
+
+
+def conv3d_k3_winograd_depth(x, wpk_wd, scale, shift, relu=False, residual=None):
     x = require_gpu_f32(x, "x")
     n, d, h, w, ci = x.shape
+    if ci != 32:
+        raise ValueError("conv3d_k3_winograd_depth takes 32 input channels (got %d)" % ci)
+    y = _new((n, d, h, w, 32), x.device)
+    if residual is not None:
+        residual = require_gpu_f32(residual, "residual")
+        if residual.shape != y.shape:
+            raise ValueError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
+    check(_lib.load().msnet_conv3d_k3_wd_f16s(ptr(x), ptr(wpk_wd), ptr(scale), ptr(shift), ptr(residual), ptr(y), n, d, h, w,
+                                              int(relu), stream_ptr()), "msnet_conv3d_k3_wd_f16s")
+    return y
+
+
+def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16s=False, wpk_wd=None):
+    x = require_gpu_f32(x, "x")
+    n, d, h, w, ci = x.shape
+    if (wpk_wd is not None and f16s and USE_WINOGRAD_DEPTH and
+            _lib.load().msnet_conv3d_k3_wd_f16s_supported(d, h, w, ci, co, stride)):
+        return conv3d_k3_winograd_depth(x, wpk_wd, scale, shift, relu=relu, residual=residual)
     od, oh, ow = (d - 1) // stride + 1, (h - 1) // stride + 1, (w - 1) // stride + 1
     y = _new((n, od, oh, ow, co), x.device)
     if residual is not None:
@@ -447,6 +483,10 @@ class ConvBNPlan:
                 w = wf * torch.exp2(k).view(shape)
                 self.scale = torch.exp2(-k).contiguous()
         self.wpk = pack_conv_weight(w, transposed, f16s=self.f16s, stride=stride)
+        # 32 -> 32 stride-1 layers also get the Winograd-depth image (same folded, pre-scaled weights; used when the shape is taken)
+        self.wpk_wd = None
+        if self.f16s and not transposed and stride == 1 and ci == 32 and self.co == 32:
+            self.wpk_wd = winograd_depth_weights(w.float())
 
 
 def state_key(module):

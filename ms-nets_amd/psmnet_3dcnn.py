@@ -117,7 +117,7 @@ class PSMNet_CostVolumeAggre(nn.Module):
         def conv(x, name, stride=1, relu=True, residual=None):
             p = pl[name]
             return hipops.conv3d_k3(x, p.wpk, p.scale, p.shift, p.co, stride=stride, relu=relu, residual=residual,
-                                     f16s=p.f16s)
+                                     f16s=p.f16s, wpk_wd=p.wpk_wd)
 
         def deconv(x, name, relu, residual):
             p = pl[name]

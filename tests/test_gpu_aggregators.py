@@ -164,6 +164,45 @@ def test_first_layer_reads_ncdhw(gpu, hiplib, co, dims, monkeypatch):
     assert guard.word() & hipops.RangeGuard.INPUT
 
 
+WD_CASES = [((1, 9, 18, 70), True, False), ((2, 8, 16, 64), True, True), ((1, 3, 5, 33), False, False), ((1, 12, 7, 37), True, True),
+            ((1, 2, 4, 32), True, False), ((1, 17, 21, 96), True, False)]
+
+
+@pytest.mark.parametrize("dims,relu,use_res", WD_CASES)
+def test_conv3d_layer_winograd_depth(gpu, hiplib, dims, relu, use_res, monkeypatch):
+    """msnet_conv3d_k3_wd_f16s (Winograd F(2,3) along depth, 32 -> 32 stride 1): against the fp64 conv at the split-fp16 gate
+    (5e-6 of the layer's magnitude) and against the direct split-fp16 kernel (not bit-identical: different summation; both are
+    within the gate of fp64).  Ragged shapes: odd depths, heights that are not multiples of 4, widths that are not multiples of 32."""
+    from msnets_amd import hipops
+    monkeypatch.setenv("MSNET_DIRECT", "0")
+    g = torch.Generator().manual_seed(sum(dims))
+    n, d, h, w = dims
+    x = torch.relu(torch.randn((n, 32, d, h, w), generator=g)) * 3
+    wt = torch.randn((32, 32, 3, 3, 3), generator=g) * (2.0 / (27 * 32)) ** 0.5
+    scale = torch.rand(32, generator=g) + 0.5
+    shift = torch.randn(32, generator=g) * 0.1
+    ref = F.conv3d(x.double(), wt.double(), None, padding=1) * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+    res = torch.randn(ref.shape, generator=g) if use_res else None
+    if use_res:
+        ref = ref + res.double()
+    if relu:
+        ref = F.relu(ref)
+    assert hiplib.msnet_conv3d_k3_wd_f16s_supported(d, h, w, 32, 32, 1) == 1
+    assert hiplib.msnet_conv3d_k3_wd_f16s_supported(d, h, w, 32, 64, 1) == 0 and hiplib.msnet_conv3d_k3_wd_f16s_supported(d, h, w, 32, 32, 2) == 0
+    wpk_wd = hipops.winograd_depth_weights(wt.cuda())
+    y = hipops.conv3d_k3_winograd_depth(_cl(x), wpk_wd, scale.cuda(), shift.cuda(), relu=relu, residual=_cl(res) if use_res else None)
+    err = _rel(_nc(y).double(), ref)
+    wpk = hipops.pack_conv_weight(wt.cuda(), f16s=True)
+    yd = hipops.conv3d_k3(_cl(x), wpk, scale.cuda(), shift.cuda(), 32, relu=relu, residual=_cl(res) if use_res else None, f16s=True)
+    errd = _rel(_nc(yd).double(), ref)
+    print("winograd-depth 32->32 %s: rel err %.2e (direct split-fp16 kernel %.2e)" % (dims, err, errd))
+    assert err < 5e-6
+    # and through conv3d_k3's dispatch (the path the modules take)
+    y2 = hipops.conv3d_k3(_cl(x), wpk, scale.cuda(), shift.cuda(), 32, relu=relu, residual=_cl(res) if use_res else None, f16s=True,
+                          wpk_wd=wpk_wd)
+    assert torch.equal(y2, y)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_conv_kernels_random_ragged_shapes(gpu, hiplib, monkeypatch, seed):
     """Random small, ragged volumes (odd depths, widths that are not multiples of 16, single rows) through every tiled

@@ -35,7 +35,9 @@ def run(name, prec, reps=5):
         wpk = hipops.pack_conv_weight(wt, f16s=f16s, stride=stride)
         od = [(v - 1) // stride + 1 for v in (d, h, w)]
         res = torch.rand((1, *od, co), device=dev) if use_res else None
-        fn = lambda: hipops.conv3d_k3(x, wpk, None, None, co, stride=stride, relu=True, residual=res, f16s=f16s)
+        wd = (hipops.winograd_depth_weights(wt) if f16s and ci == 32 and co == 32 and stride == 1 and
+              os.environ.get("MSNET_LB_WD", "1") != "0" else None)         # MSNET_LB_WD=0: the direct split-fp16 kernel
+        fn = lambda: hipops.conv3d_k3(x, wpk, None, None, co, stride=stride, relu=True, residual=res, f16s=f16s, wpk_wd=wd)
         vox = od[0] * od[1] * od[2]
     else:
         wt = (torch.randn((ci, co, 3, 3, 3), generator=g) * 0.05).to(dev)
