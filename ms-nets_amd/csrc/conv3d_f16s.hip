@@ -2209,6 +2209,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
             const Coord c0 = coord_of(cur);
             issue(S[0][0], c0, 0, true); issue(S[0][1], c0, 1, true); issue(S[1][0], c0, 2, true); issue(S[1][1], c0, 3, true);
             WD_ISSUE_B(0, bw[0]);
+            WD_WRITE_B(0, bw[0]);                       // (nobody reads the weight buffers before the first b2)
+            WD_ISSUE_B(1, bw[0]);
         }
         bool early = false;                             // q0..q2 of the current tile were written under the previous tile's groups
         auto item = [&](auto parc, const int it) {
@@ -2223,9 +2225,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
             // the next tile's p2 goes into this tile's p0 registers (dead once q0 is written): requested here already, two and a
             // half groups before its first use; p3 follows behind b2 into the p1 registers, which q3 below still reads
             issue(S[P][0], nx, 2, more);
-            write_q(I3{}, S[P], S[1 - P]);
-            WD_WRITE_B(0, bw[0]);
-            WD_ISSUE_B(1, bw[0]);
+            write_q(I3{}, S[P], S[1 - P]);             // (weight group 0 was copied under the previous tile's last group)
             STAMP(wave, sidx, lane);
             MSNET_LDS_BARRIER();                        // b2: tile and weight group 0 are in LDS
             STAMP(wave, sidx, lane);
@@ -2256,6 +2256,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
             MSNET_LDS_BARRIER();                        // g4: taps ..29 done, q2 is dead
             STAMP(wave, sidx, lane);
             if (ncont) write_q(I2{}, S[1 - P], S[P]);
+            WD_WRITE_B(6, bw[0]); WD_ISSUE_B(7, bw[0]);      // the next tile's group 0 into buffer 0 (free since g4), its group 1 requested
             early = ncont;
             cur = nxt; nxt.next();
         };
