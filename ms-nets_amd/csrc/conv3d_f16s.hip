@@ -2586,7 +2586,7 @@ extern "C" int msnet_conv3d_k3_wd_f16s(const float* x, const void* wpk_wd, const
     a.x = x; a.wpk = reinterpret_cast<const f32x4*>(wpk_wd); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = 32; a.Co = 32; a.relu = relu; a.oflag = overflow_flag();
     a.OD = D; a.OH = H; a.OW = W;
-    const int rc = launch_wd_f16s("conv3d_s1_f16s_co32", a, (hipStream_t)stream);
+    const int rc = launch_wd_f16s("conv3d_s1_wd_f16s", a, (hipStream_t)stream);
     if (rc < 0) return fail("msnet_conv3d_k3_wd_f16s: a sample exceeds the kernel's 32-bit offset range");
     return rc;
 }

@@ -1,4 +1,4 @@
-"""Aggregates the FETCH_SIZE / WRITE_SIZE passes of tools_pmc_traffic.sh into profiles/r02_pmc_traffic.json (stdout) and a
+"""Aggregates the FETCH_SIZE / WRITE_SIZE passes of tools_pmc_traffic.sh into profiles/r03_pmc_traffic.json (stdout) and a
 per-kernel table (stderr).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half
 their bytes (MI355X_MICROARCH.md, HBM) and is doubled here, WRITE_SIZE is exact for 16-byte-per-lane stores."""
 import collections, csv, glob, hashlib, json, os, sys
@@ -40,11 +40,13 @@ def pick(pred):
 
 
 out = {}
-dom = pick(lambda k: "conv3d_k3s1_f16s_ws" in k and "true, 4>" in k.replace("(bool)1", "true"))      # the sliding-window (32->32) instantiation
+dom = pick(lambda k: "conv3d_wd_f16s_kernel" in k)          # conv3dbn_2: the Winograd-depth kernel ...
+if not dom:
+    dom = pick(lambda k: "conv3d_k3s1_f16s_ws" in k and "true, 4>" in k.replace("(bool)1", "true"))      # ... or the sliding-window direct kernel
 if dom:
     k, n, fb, wb = dom[0]
     mf = sq["SQ_VALU_MFMA_BUSY_CYCLES"].get(k); bz = sq["SQ_BUSY_CYCLES"].get(k); gr = sq["GRBM_GUI_ACTIVE"].get(k)
-    out["conv3d_s1_f16s_co32"] = {
+    out["conv3d_s1_wd_f16s" if "conv3d_wd_f16s_kernel" in k else "conv3d_s1_f16s_co32"] = {
         "workload": "cfg2", "batch_per_gpu": 1, "sources": ["conv3d_f16s.hip", "conv_common.h"], "source_sha16": sha(["conv3d_f16s.hip", "conv_common.h"]),
         "kernel": k, "hbm_bytes": fb + wb, "fetch_bytes_x2": fb, "write_bytes": wb,
         "algorithmic_bytes": 2.0 * 96 * 272 * 480 * 32 * 4,
