@@ -2379,13 +2379,21 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
             constexpr int s = decltype(sc_)::value, T = s / 2, ks = s % 2, k = T / 9, kh = (T % 9) / 3, kw = T % 3;
             constexpr int IMM = ((kh * 4 + k) * IW) * RB;
             ah[s % 3] = *reinterpret_cast<const half8*>(abase_hi[kw][ks] + IMM);
+#if defined(EXP_WD_SKIP_AL)          // timing experiment only (wrong results): how much the LDS fragment reads cost
+            al[s % 3] = ah[s % 3];
+#else
             al[s % 3] = *reinterpret_cast<const half8*>(abase_lo[kw][ks] + IMM);
+#endif
         };
         auto frag_b = [&](auto sc_) {
             constexpr int s = decltype(sc_)::value, T = s / 2, ks = s % 2, g = T / 6, t = T % 6;
             constexpr int IMM = (g & 1) * GB + ((t * 2 + ks) * 2) * 1024;
             bh_[s % 3] = *reinterpret_cast<const half8*>(bbase + IMM);
+#if defined(EXP_WD_SKIP_BL)
+            bl[s % 3] = bh_[s % 3];
+#else
             bl[s % 3] = *reinterpret_cast<const half8*>(bbase + IMM + 1024);
+#endif
         };
         frag_a(std::integral_constant<int, 0>{}); frag_b(std::integral_constant<int, 0>{});
         frag_a(std::integral_constant<int, 1>{}); frag_b(std::integral_constant<int, 1>{});
