@@ -93,5 +93,13 @@ def test_bench_roofline_step_and_profile_facts(gpu):
     r = d["roofline"]
     for k in ("frac_rocprof", "avg_launch_ms_rocprof", "sustained_clock_ghz", "profile_facts"):
         assert k in r
+    # the peak follows the algorithm of the launch that ran: 2500 / executed fp16 MFMAs per algorithmic (direct-conv) product --
+    # 3 for the direct split-fp16 kernel, 2 for the Winograd-depth kernel; the 2500/3 ratio of rounds 1-2 is a separate field
+    m = r["mfmas_per_algorithmic_product"]
+    assert m in (2.0, 3.0) and abs(r["peak"] - 2500.0 / m) < 1e-6
+    assert ("Winograd" in r["kernel"]) == (m == 2.0)
+    assert abs(r["frac_of_direct_split_peak"] - r["achieved"] / (2500.0 / 3)) < 1e-9
+    assert 2.0 < rs["mfmas_per_algorithmic_product"] <= 3.0 and abs(rs["peak"] - 2500.0 / rs["mfmas_per_algorithmic_product"]) < 1e-6
+    assert abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-9
     if r["frac_rocprof"] is not None:
         assert abs(r["frac_rocprof"] - r["frac"]) < 0.1 and 1.0 < r["sustained_clock_ghz"] < 2.6
