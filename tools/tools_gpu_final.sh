@@ -17,7 +17,8 @@ python tools/tools_profile_facts.py $(find $OUT/${TAG}_prof -name "*kernel_stats
 python -m pytest tests -m gpu -q --timeout 1800 -s 2>&1 | grep -E "max\||rel err|full size|cfg|likelihood|K gate|passed|failed|FAILED|Error|error" | tail -200 > $OUT/${TAG}_pytest.log
 python bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python bench.py --steps 10 --warmup 3 --verbose --no-cpu-baseline --no-extras > $OUT/${TAG}_benchv.json 2> $OUT/${TAG}_benchv.err
-python bench.py --steps 10 --warmup 3 --verbose --workload cfg3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_cfg3.json 2> $OUT/${TAG}_bench_cfg3.err
+python bench.py --steps 10 --warmup 3 --verbose --workload cfg3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_cfg3v.json 2> $OUT/${TAG}_bench_cfg3.err
+python bench.py --steps 20 --warmup 3 --workload cfg3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_cfg3.json 2>/dev/null
 python bench.py --steps 10 --warmup 3 --workload cfg5 --batch-per-gpu 2 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_cfg5.json 2>/dev/null
 python bench.py --steps 5 --warmup 2 --batch-per-gpu 4 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_cfg4.json 2>/dev/null
 python bench.py --gpus 1 --self-launch --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_selflaunch.json 2>/dev/null
