@@ -2579,6 +2579,8 @@ extern "C" int msnet_pack_conv_weight_wd_f16s(const float* g36, void* packed, ms
 // 1 when msnet_conv3d_k3_wd_f16s takes the layer: stride 1, 32 -> 32 channels, and large enough for the tiled kernels
 extern "C" int msnet_conv3d_k3_wd_f16s_supported(int D, int H, int W, int Ci, int Co, int stride) {
     if (stride != 1 || Ci != 32 || Co != 32 || D < 2) return 0;
+    // 32-bit byte offsets inside a sample (drained stores, loader descriptor): larger samples take the direct kernel
+    if ((size_t)D * H * W * Co * 4 > 0xfffffff0u || (size_t)D * H * W * Ci * 4 > 0x7ffffff0u) return 0;
     ConvArgs a{};
     a.D = a.OD = D; a.H = a.OH = H; a.W = a.OW = W; a.Ci = Ci; a.Co = Co; a.N = 1;
     const size_t items = (size_t)cdiv(D, 2) * cdiv(H, 4) * cdiv(W, 32);

@@ -39,6 +39,12 @@ def test_argument_validation_needs_no_gpu(hiplib):
     assert hiplib.msnet_packed_weight_floats(32, 64) == 27 * 32 * 64
     assert hiplib.msnet_sadsob_workspace_bytes(292, 500, 96) == 96 * 293 * 501 * 4
     assert hiplib.msnet_build_volume_workspace_bytes(0, 5, 5) == 0
+    # which shapes the Winograd-depth kernel takes (host-side predicate; the Python dispatch falls back to the direct kernels)
+    sup = hiplib.msnet_conv3d_k3_wd_f16s_supported
+    assert sup(96, 272, 480, 32, 32, 1) == 1 and sup(95, 271, 479, 32, 32, 1) == 1
+    assert sup(96, 272, 480, 32, 64, 1) == 0 and sup(96, 272, 480, 64, 64, 1) == 0 and sup(96, 272, 480, 32, 32, 2) == 0
+    assert sup(1, 272, 480, 32, 32, 1) == 0
+    assert sup(128, 272, 480, 32, 32, 1) == 1 and sup(132, 272, 480, 32, 32, 1) == 0      # a sample must stay below 2 GiB
 
 
 def test_product_path_has_no_cpu_fallback():

@@ -203,6 +203,30 @@ def test_conv3d_layer_winograd_depth(gpu, hiplib, dims, relu, use_res, monkeypat
     assert torch.equal(y2, y)
 
 
+def test_winograd_depth_full_size_is_deterministic(gpu, hiplib):
+    """conv3dbn_2's shape (96 x 272 x 480, 32 -> 32): the persistent kernel's loader / MFMA wave hand-offs (q planes rewritten under
+    the running tile, weight groups double-buffered, drained stores of the previous tile) leave no run-to-run freedom -- three
+    launches on the same input are bit-identical -- and the result agrees with the direct split-fp16 kernel to the layer gate."""
+    from msnets_amd import hipops
+    g = torch.Generator().manual_seed(77)
+    d, h, w = 96, 272, 480
+    x = torch.relu(torch.randn((1, d, h, w, 32), generator=g)).cuda()             # NDHWC as the kernels take it
+    wt = torch.randn((32, 32, 3, 3, 3), generator=g) * (2.0 / (27 * 32)) ** 0.5
+    scale, shift = (torch.rand(32, generator=g) + 0.5).cuda(), (torch.randn(32, generator=g) * 0.1).cuda()
+    assert hiplib.msnet_conv3d_k3_wd_f16s_supported(d, h, w, 32, 32, 1) == 1
+    wpk_wd = hipops.winograd_depth_weights(wt.cuda())
+    y0 = hipops.conv3d_k3_winograd_depth(x, wpk_wd, scale, shift, relu=True)
+    for _ in range(2):
+        y = hipops.conv3d_k3_winograd_depth(x, wpk_wd, scale, shift, relu=True)
+        assert torch.equal(y, y0)
+        del y
+    wpk = hipops.pack_conv_weight(wt.cuda(), f16s=True)
+    yd = hipops.conv3d_k3(x, wpk, scale, shift, 32, relu=True, f16s=True)
+    err = float((yd - y0).abs().max() / yd.abs().max())
+    print("winograd-depth vs direct split-fp16 at 96x272x480: max rel diff %.2e" % err)
+    assert err < 5e-6
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_conv_kernels_random_ragged_shapes(gpu, hiplib, monkeypatch, seed):
     """Random small, ragged volumes (odd depths, widths that are not multiples of 16, single rows) through every tiled
