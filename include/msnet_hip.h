@@ -43,9 +43,12 @@ int         msnet_prof_enable(int on);
 int         msnet_prof_select(const char* name_prefix);
 long        msnet_prof_collect(char* buf_host, size_t buf_bytes);
 
-/* fp16-range guard of the split-fp16 kernels (their operands' `hi` halves are fp16: |x| must stay below 65504).  While a
- * device word is registered (per calling thread; NULL unregisters) every conv / transposed-conv epilogue and the NCDHW ->
- * NDHWC conversion of the module input OR a bit into it when they store / read a magnitude >= 65504 (or a non-finite value):
+/* Range guard of the split-fp16 kernels.  Their operands' `hi` halves are fp16, and the Winograd-depth kernel splits sums and
+ * differences of two activations, so an activation must stay below 32752 (half the largest finite fp16; BN-folded weights:
+ * below 65504, checked by the caller when it packs them).  While a device word is registered (per calling thread; NULL
+ * unregisters) every conv / transposed-conv epilogue ORs bit 0 into it when it stores a magnitude >= 32752 (or inf), and the
+ * NCDHW -> NDHWC conversion of the module input and the NCDHW first-layer loader OR bit 1 into it when they read a magnitude
+ * >= 32752, an inf or a NaN:
  * bit 0 = an activation (conv / transposed-conv epilogues), bit 1 = the module input (layout conversion, first-layer loader).
  * The caller zeroes the word, runs the layers, reads it back; ms-nets_amd/hipops.py re-runs the forward on the exact
  * fp32 kernels when it is set.  No reference counterpart: torch's fp32 conv has no such range limit. */

@@ -35,13 +35,18 @@ struct ConvArgs {
     int stagger;           // -DEXP_STAGGER builds only: start delay per workgroup phase (blockIdx & 3) in units of 1024 cycles
 };
 
-// Range guard of the split-fp16 kernels (conv3d_f16s.hip: every operand's `hi` half is an fp16): an activation of magnitude
-// >= 65504 cannot be split.  Every epilogue folds the magnitudes it stores into one compare and raises the caller's flag;
-// the Python modules then re-run the forward on the exact fp32 kernels (hipops.py).  16 v_max + 1 compare per 16 outputs.
-constexpr float kF16Max = 65504.f;
+// Range guard of the split-fp16 kernels (conv3d_f16s.hip: every operand's `hi` half is an fp16).  The limit is HALF the largest
+// finite fp16: the Winograd-depth loaders split sums and differences of two activations (q1 = p1 + p2, ...), and those must
+// stay finite as fp16 too; below 32752 every kernel of the file is safe.  Every epilogue folds the magnitudes it stores into one
+// compare and raises the caller's flag; the Python modules then re-run the forward on the exact fp32 kernels (hipops.py).
+// 16 v_max + 1 compare per 16 outputs.  (v_max drops a NaN: a NaN never shows in `amax`.  With in-range operands none can arise
+// -- they come from a non-finite module INPUT, which the input checks below report through the magnitude BITS.)
+constexpr float kSplitMax = 32752.f;
+constexpr unsigned kSplitMaxBits = 0x46ffe000u;             // bits of 32752.f: (bits & 0x7fffffff) >= this <=> |x| >= 32752, inf or NaN
 __device__ __forceinline__ void flag_overflow(unsigned* oflag, float amax) {
-    if (oflag && !(amax < kF16Max)) atomicOr(oflag, 1u);      // !(x < max): also catches inf and NaN maxima
+    if (oflag && !(amax < kSplitMax)) atomicOr(oflag, 1u);    // (inf maxima included)
 }
+__device__ __forceinline__ unsigned magnitude_bits(float v) { return __builtin_bit_cast(unsigned, v) & 0x7fffffffu; }
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);

@@ -35,18 +35,20 @@ __global__ __launch_bounds__(256) void ncs_to_nsc_kernel(const float* __restrict
     const int tid = threadIdx.x;
     const int cnt = (int)((S - s0 < 256) ? (S - s0) : 256);
     const float* sp = src + (size_t)n * C * S + s0;
-    float amax = 0.f;                                      // the module input feeds a split-fp16 layer: fp16 range guard
+    unsigned amax = 0u;                                    // the module input feeds a split-fp16 layer: range guard on the magnitude BITS (NaN-aware)
     int c = 0;
     for (; c + 8 <= C; c += 8) {                           // eight independent plane loads in flight per thread
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = tid < cnt ? sp[(size_t)(c + u) * S + tid] : 0.f;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { amax = fmaxf(amax, fabsf(v[u])); tile[(c + u) * LS + tid] = v[u]; }
+        for (int u = 0; u < 8; ++u) { amax = max(amax, __builtin_bit_cast(unsigned, v[u]) & 0x7fffffffu); tile[(c + u) * LS + tid] = v[u]; }
     }
     for (; c < C; ++c)
-        if (tid < cnt) { const float v = sp[(size_t)c * S + tid]; amax = fmaxf(amax, fabsf(v)); tile[c * LS + tid] = v; }
-    if (oflag && !(amax < 65504.f)) atomicOr(oflag, 2u);    // bit 1: the module INPUT left the range (a per-call condition, hipops.py)
+        if (tid < cnt) { const float v = sp[(size_t)c * S + tid]; amax = max(amax, __builtin_bit_cast(unsigned, v) & 0x7fffffffu); tile[c * LS + tid] = v; }
+    // bit 1: the module INPUT left the range of the split-fp16 kernels (|x| >= 32752, conv_common.h), or is inf / NaN -- a per-call
+    // condition (hipops.py)
+    if (oflag && amax >= 0x46ffe000u) atomicOr(oflag, 2u);
     __syncthreads();
     float* dp = dst + ((size_t)n * S + s0) * C;
     const int total = cnt * C;

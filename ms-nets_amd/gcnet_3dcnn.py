@@ -78,7 +78,7 @@ class GCNet_CostVolumeAggre(nn.Module):
         self._plan = None
         self._plan_key = None
         # fp16-range guard of the split-fp16 kernels (hipops.guarded_forward): costs one 4-byte read-back per forward;
-        # set range_check = False when the activations are known to stay below 65504
+        # set range_check = False when the activations are known to stay below 32752 (hipops.ACT_MAX)
         self.range_check = os.environ.get("MSNET_RANGE_CHECK", "1") != "0"
         self._forced_precision = None
         self._guard = None

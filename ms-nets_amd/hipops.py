@@ -104,7 +104,10 @@ def pack_conv_weight(w, transposed=False, f16s=False, stride=1):
     return out
 
 
-F16S_MAX = 65504.0      # largest finite fp16: |operand| of a split-fp16 kernel must stay below it (hi = fp16(x))
+F16S_MAX = 65504.0      # largest finite fp16: a BN-folded WEIGHT of a split-fp16 kernel must stay below it (hi = fp16(w))
+# Activations (and the module input) must stay below HALF of it: the Winograd-depth kernel splits sums / differences of two
+# activations.  The kernels' epilogues and the input conversion compare against this value (csrc/conv_common.h: kSplitMax).
+ACT_MAX = 32752.0
 PRECISIONS = ("fp32", "split-fp16")
 _default_precision = "split-fp16"
 # Transposed convs with a split-fp16 kernel use it: Ci = 64 on the tiled kernel (1.22 vs 1.99 ms on deconvbn4, 0.28 vs
@@ -321,8 +324,9 @@ def _range_fallback(module, run, word):
     so one bad sample in a serving loop does not move the module onto the slower path for good."""
     # (a bad input usually drags activations out of range with it: only a trip WITHOUT the input bit is the weights' doing)
     sticky = not (word & RangeGuard.INPUT)
-    warnings.warn("msnet: %s left the fp16 range (|x| >= 65504) of the split-fp16 conv kernels; this forward was repeated on the "
-                  "exact fp32 MFMA kernels%s" % ("an activation" if sticky else "the module input",
+    warnings.warn("msnet: %s left the fp16 range of the split-fp16 conv kernels (|x| >= %g%s); this forward was repeated on the "
+                  "exact fp32 MFMA kernels%s" % ("an activation" if sticky else "the module input", ACT_MAX,
+                                                 "" if sticky else ", inf or NaN",
                                                  ", which this module now keeps using" if sticky else " (this call only)"),
                   RuntimeWarning)
     if sticky:

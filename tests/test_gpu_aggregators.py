@@ -705,6 +705,51 @@ def test_fp16_range_guard_reruns_on_fp32(gpu):
     assert ok._forced_precision is None
 
 
+def test_winograd_input_range_is_guarded(gpu, monkeypatch):
+    """The Winograd-depth kernel splits SUMS of two activations (q1 = p1 + p2): inputs between 32752 and 65504 -- finite as fp16
+    themselves -- can overflow its `hi` halves.  The guard's limit is therefore 32752 in every epilogue: a conv3dbn_1 output
+    of ~48 000 (compensated in conv3dbn_2's weights) trips it, the forward is repeated on fp32 and matches the oracle."""
+    monkeypatch.setenv("MSNET_DIRECT", "0")             # tiled kernels at this size: conv3dbn_2 runs the Winograd-depth kernel
+    G, _ = _our_classes()
+    torch.manual_seed(21)
+    m = G(32).eval()
+    recipes.randomize_bn(m, 21)
+    x = torch.rand((1, 8, 16, 16, 32), generator=torch.Generator().manual_seed(22))
+    with torch.no_grad():
+        a1 = float(F.relu(m.conv3dbn_1(x)).max())
+        scale = 48000.0 / a1
+        m.conv3dbn_1[1].weight.mul_(scale)
+        m.conv3dbn_1[1].bias.mul_(scale)
+        m.conv3dbn_2[0].weight.div_(scale)
+        a1 = float(F.relu(m.conv3dbn_1(x)).max())
+    assert 33000.0 < a1 < 60000.0                       # inside the fp16 range, outside the split-fp16 kernels' limit
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = oracle.gcnet_forward(sd, x, 32)
+    m = m.cuda()
+    with pytest.warns(RuntimeWarning, match="an activation"):
+        got = m(x.cuda()).cpu()
+    assert m._forced_precision == "fp32"
+    assert float((got - ref).abs().max()) <= DISP_TOL
+
+
+def test_nonfinite_module_input_is_reported(gpu):
+    """A NaN or inf voxel in the module input raises the INPUT bit of the range guard (the checks compare magnitude bits: v_max
+    alone would drop the NaN): a warning names the module input, the call is repeated on fp32, the module stays on split-fp16."""
+    G, _ = _our_classes()
+    torch.manual_seed(23)
+    m = G(32).eval().cuda()
+    x = torch.rand((1, 8, 16, 16, 32), generator=torch.Generator().manual_seed(24)).cuda()
+    good = m(x).clone()
+    for bad in (float("nan"), float("inf"), -4.0e4):
+        xb = x.clone()
+        xb[0, 3, 7, 5, 11] = bad
+        with pytest.warns(RuntimeWarning, match="module input"):
+            m(xb)
+        assert m._forced_precision is None
+    assert torch.equal(m(x), good)
+
+
 @pytest.mark.parametrize("ci,co,stride,transposed", [(32, 32, 1, False), (64, 64, 1, False), (8, 32, 1, False), (32, 64, 2, False),
                                                       (64, 32, 1, True), (128, 128, 1, False)])
 @pytest.mark.parametrize("xs,ws", [(1.0e-5, 1.0), (1.0, 1.0e-5), (1.0e-5, 1.0e-5), (3.0e-4, 1.0e-3)])
@@ -881,10 +926,10 @@ def test_graphed_forward_range_guard(gpu):
         z = model(x)
     model.use_graph = False
     assert torch.equal(z, model(x))
-    # activation trip under replay: the same buffer now holds values just inside the fp16 range, so the INPUT passes but the
+    # activation trip under replay: the same buffer now holds values just inside the kernels' range (32752), so the INPUT passes but the
     # first conv's outputs do not: sticky, graphs dropped
     model.use_graph = True
-    x.mul_(6.0e4)
+    x.mul_(3.0e4)
     with pytest.warns(RuntimeWarning, match="an activation"):
         w = model(x)
     assert bool(torch.isfinite(w).all()) and model._forced_precision == "fp32" and not model._graphs
