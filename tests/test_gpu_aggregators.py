@@ -792,11 +792,14 @@ def test_split_fp16_small_magnitudes(gpu, ci, co, stride, transposed, xs, ws):
     assert err < 5e-6
 
 
-def test_small_activations_end_to_end(gpu):
+@pytest.mark.parametrize("direct", [None, "0"])
+def test_small_activations_end_to_end(gpu, direct, monkeypatch):
     """Underflow twin of test_fp16_range_guard_reruns_on_fp32 at the module level: conv3dbn_2's output (= the res_l20 skip
     connection) and its folded weights are scaled to ~1e-5, compensated downstream.  The split-fp16 forward must still match
     the oracle to 1e-3 -- with no fallback (no warning, no fp32 re-run)."""
     import warnings
+    if direct is not None:
+        monkeypatch.setenv("MSNET_DIRECT", direct)      # "0": tiled kernels at this size -- conv3dbn_2 on the Winograd-depth kernel
     m = _big_activation_model(1.0e-5)
     sd = {k: v.clone() for k, v in m.state_dict().items()}
     x = torch.rand((1, 8, 16, 16, 32), generator=torch.Generator().manual_seed(12))
@@ -811,6 +814,35 @@ def test_small_activations_end_to_end(gpu):
     assert m._forced_precision is None
     err = float((got - ref).abs().max())
     print("small activations end to end: max|disp - oracle| = %.3e" % err)
+    assert err <= DISP_TOL
+
+
+def test_small_activations_into_winograd_layer(gpu, monkeypatch):
+    """The other side of the Winograd-depth layer: its INPUT (conv3dbn_1's output) scaled to ~1e-5, its weights up by the same
+    factor.  q = p1 + p2 etc. are formed in fp32 and split like any activation; no fallback, result within 1e-3 of the oracle."""
+    import warnings
+    monkeypatch.setenv("MSNET_DIRECT", "0")
+    G, _ = _our_classes()
+    torch.manual_seed(31)
+    m = G(32).eval()
+    recipes.randomize_bn(m, 31)
+    with torch.no_grad():
+        m.conv3dbn_1[1].weight.mul_(1.0e-5)
+        m.conv3dbn_1[1].bias.mul_(1.0e-5)
+        m.conv3dbn_2[0].weight.mul_(1.0e5)
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    x = torch.rand((1, 8, 16, 16, 32), generator=torch.Generator().manual_seed(32))
+    with torch.no_grad():
+        taps_or = {}
+        ref = oracle.gcnet_forward(sd, x, 32, taps=taps_or)
+    assert float(taps_or["conv3dbn_1"].abs().max()) < 2e-4
+    m = m.cuda()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = m(x.cuda()).cpu()
+    assert m._forced_precision is None
+    err = float((got - ref).abs().max())
+    print("small activations into the Winograd-depth layer: max|disp - oracle| = %.3e" % err)
     assert err <= DISP_TOL
 
 
