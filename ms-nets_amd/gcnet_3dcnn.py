@@ -94,6 +94,7 @@ class GCNet_CostVolumeAggre(nn.Module):
         self._plan_key = None
         self._forced_precision = None
         self.__dict__.pop("_graphs", None)        # captured HIP graphs hold the old packed weights
+        self.__dict__.pop("_state_tensors", None)  # hipops.state_key re-walks the module tree
 
     def _plans(self, precision):
         key = hipops.state_key(self)
@@ -168,6 +169,7 @@ class GCNet_CostVolumeAggre(nn.Module):
             x = deconv(x, "deconvbn2", res_l26)
             x = deconv(x, "deconvbn3", res_l23)
             x = deconv(x, "deconvbn4", res_l20)
+            hipops.guard_checkpoint()                 # the tail kernels below have no range check: read the guard word back under them
             s = 4 if self.is_quarter_input_size else 2
             depth = s * x.shape[1]
             assert depth == self.maxdisp, "%d != %d" % (depth, self.maxdisp)   # gcnet_3dcnn.py:135

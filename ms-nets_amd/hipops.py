@@ -2,6 +2,8 @@
 memory (torch.empty) and the current HIP stream; all arithmetic happens in libmsnet_hip.so.
 
 Internal activation layout is channels-last fp32 [N, D, H, W, C] ("NDHWC")."""
+import os
+import threading
 import warnings
 
 import torch
@@ -272,6 +274,21 @@ def trilinear_softargmin(cost, out_dhw):
     return disp
 
 
+class _ActiveGuard(threading.local):
+    guard = None
+
+
+_active_guard = _ActiveGuard()          # the RangeGuard of the forward running on this thread (the library's flag is per thread too)
+EARLY_READBACK = os.environ.get("MSNET_EARLY_READBACK", "1") != "0"      # A/B switch (same result either way)
+
+
+def guard_checkpoint():
+    """Modules call this behind their last launch that can raise the range flag (see RangeGuard.checkpoint)."""
+    g = _active_guard.guard
+    if g is not None and EARLY_READBACK:
+        g.checkpoint()
+
+
 class RangeGuard:
     """fp16-range guard for one forward on the split-fp16 kernels: registers a device word with the library
     (msnet_set_overflow_flag); every conv epilogue ORs bit 0 into it when it stores a magnitude the split (hi = fp16(x)) cannot
@@ -281,17 +298,42 @@ class RangeGuard:
 
     def __init__(self, device):
         self.flag = torch.zeros(1, dtype=torch.int32, device=device)
+        self._host = None                   # pinned word + event of an early read-back (checkpoint)
+        self._event = None
+        self._pending = False
 
     def __enter__(self):
         self.flag.zero_()
+        self._pending = False
         check(_lib.load().msnet_set_overflow_flag(ptr(self.flag)), "msnet_set_overflow_flag")
+        _active_guard.guard = self
         return self
 
     def __exit__(self, *exc):
+        _active_guard.guard = None
         _lib.load().msnet_set_overflow_flag(None)
         return False
 
+    def checkpoint(self):
+        """Start the read-back NOW: the caller promises that no launch after this point can raise the flag (the modules call
+        it behind their last conv, in front of the tail kernels, which have no range check).  word() then waits for this
+        copy only, i.e. the host learns the verdict while the tail is still running and prepares the next forward under it
+        instead of behind it (the wait at the end of a forward otherwise exposes ~0.2 ms of host work per forward).
+        Not inside a graph capture (the replay path reads the word after the replay)."""
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self._host is None:
+            self._host = torch.zeros(1, dtype=torch.int32).pin_memory()
+            self._event = torch.cuda.Event()
+        self._host.copy_(self.flag, non_blocking=True)
+        self._event.record()
+        self._pending = True
+
     def word(self):
+        if self._pending:
+            self._pending = False
+            self._event.synchronize()
+            return int(self._host[0])
         return int(self.flag.item())
 
     def tripped(self):
@@ -493,9 +535,28 @@ class ConvBNPlan:
             self.wpk_wd = winograd_depth_weights(w.float())
 
 
+def _registered_tensors(module):
+    """[(owner dict, name, tensor)] for every parameter / buffer registered in the module tree."""
+    out = []
+    for mod in module.modules():
+        for d in (mod._parameters, mod._buffers):
+            for name, t in d.items():
+                if t is not None:
+                    out.append((d, name, t))
+    return out
+
+
 def state_key(module):
     """Cheap fingerprint of a module's parameters/buffers (data pointer, version counter, device): the packed weights and BN
     plans are rebuilt when it changes.  load_state_dict, .to(), copy_ and every autograd-visible in-place op bump it.
     Edits made THROUGH `.data` (p.data.mul_(2), the idiom of the reference's net_init.py) do NOT bump the version counter;
-    after such an edit call `model.invalidate_plans()`."""
-    return tuple((t.data_ptr(), t._version, t.device.index) for t in list(module.parameters()) + list(module.buffers()))
+    after such an edit call `model.invalidate_plans()`.
+    Called once or twice per forward, on the host path between two forwards: walking the module tree (140 us for the 110
+    tensors of the GCNet aggregator) is done once; afterwards the registered tensors are re-checked by identity (a re-assigned
+    parameter or buffer is a different object in its owner's dict) and only pointers and version counters are read (~30 us).
+    Submodules added after the first forward are not seen: invalidate_plans() re-walks the tree."""
+    cache = module.__dict__.get("_state_tensors")
+    if cache is None or not all(d.get(name) is t for d, name, t in cache):
+        cache = module.__dict__["_state_tensors"] = _registered_tensors(module)
+    ts = [c[2] for c in cache]
+    return (tuple(map(torch.Tensor.data_ptr, ts)), tuple(t._version for t in ts), ts[0].device if ts else None)

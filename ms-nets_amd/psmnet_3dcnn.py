@@ -80,6 +80,7 @@ class PSMNet_CostVolumeAggre(nn.Module):
         self._plan_key = None
         self._forced_precision = None
         self.__dict__.pop("_graphs", None)        # captured HIP graphs hold the old packed weights
+        self.__dict__.pop("_state_tensors", None)  # hipops.state_key re-walks the module tree
 
     def _plans(self, precision):
         key = hipops.state_key(self)
@@ -148,7 +149,9 @@ class PSMNet_CostVolumeAggre(nn.Module):
         tap("out3", out3)
         cost1 = hipops.conv3d_k3_cout1(conv(out1, "classif1.0"), pl["classif1.2"], wscale=pl["classif1.2.wsc"])
         cost2 = hipops.conv3d_k3_cout1(conv(out2, "classif2.0"), pl["classif2.2"], add=cost1, wscale=pl["classif2.2.wsc"])
-        cost3 = tap("cost3", hipops.conv3d_k3_cout1(conv(out3, "classif3.0"), pl["classif3.2"], add=cost2, wscale=pl["classif3.2.wsc"]))
+        c3 = conv(out3, "classif3.0")
+        hipops.guard_checkpoint()                     # the last launch with a range check: read the guard word back under the tail
+        cost3 = tap("cost3", hipops.conv3d_k3_cout1(c3, pl["classif3.2"], add=cost2, wscale=pl["classif3.2.wsc"]))
         return cost1, cost2, cost3
 
     def _check(self, cost):
