@@ -292,8 +292,9 @@ def guard_checkpoint():
 class RangeGuard:
     """fp16-range guard for one forward on the split-fp16 kernels: registers a device word with the library
     (msnet_set_overflow_flag); every conv epilogue ORs bit 0 into it when it stores a magnitude the split (hi = fp16(x)) cannot
-    represent, the layout conversion of the module INPUT ORs bit 1.  `word()` reads it back (one 4-byte device-to-host copy
-    = one sync per forward)."""
+    represent (|x| >= ACT_MAX), the layout conversion of the module INPUT ORs bit 1.  `word()` reads it back: one 4-byte
+    device-to-host copy per forward, started by `checkpoint()` behind the last range-checked launch and waited for under the
+    tail kernels (without a checkpoint: a plain read-back after the last launch)."""
     ACTIVATION, INPUT = 1, 2
 
     def __init__(self, device):
