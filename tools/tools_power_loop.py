@@ -14,8 +14,10 @@ if mode == "relu": x = torch.relu(x - 0.5) * 2
 if mode == "zeros": x.zero_(); wt.zero_()
 x, wt = x.cuda(), wt.cuda()
 wpk = hipops.pack_conv_weight(wt, f16s=True, stride=stride)
+# 32 -> 32 stride 1: the Winograd-depth kernel, as in the modules (MSNET_LB_WD=0: the direct kernel)
+wd = hipops.winograd_depth_weights(wt) if (ci, co, stride) == (32, 32, 1) and os.environ.get("MSNET_LB_WD", "1") != "0" else None
 t0 = time.time(); n = 0
 while time.time() - t0 < secs:
-    for _ in range(50): hipops.conv3d_k3(x, wpk, None, None, co, stride=stride, relu=True, f16s=True)
+    for _ in range(50): hipops.conv3d_k3(x, wpk, None, None, co, stride=stride, relu=True, f16s=True, wpk_wd=wd)
     torch.cuda.synchronize(); n += 50
-print("%s %s: %.3f ms per launch over %.1f s" % (name, mode, 1e3 * (time.time() - t0) / n, time.time() - t0))
+print("%s %s%s: %.3f ms per launch over %.1f s" % (name, mode, " (winograd-depth)" if wd is not None else "", 1e3 * (time.time() - t0) / n, time.time() - t0))
