@@ -2192,17 +2192,32 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
             }
         };
         struct BSet { u32x4 v0, v1, v2, v3, v4, v5; };
-        BSet bw[1];    // one set: group g+1 is copied to LDS in slot g and group g+2 requested right behind it (weights are L2-resident)
+        // one set: group g+1 is copied to LDS in slot g and group g+2 requested right behind it (weights are L2-resident).  A second set
+        // (two slots of flight) is no faster: 1.577 vs 1.574-1.589 ms in the network (and with 64-bit-address loads it spilled: 1.90 ms).
+        BSet bw[1];
+#ifdef EXP_WD_GLOBAL_B
 #define WD_ISSUE_B(GRP, SET)                                                                                        \
     do { const u32x4* src_ = wg + (size_t)((GRP) % 6) * PG + lt;                                                    \
          SET.v0 = src_[0]; SET.v1 = src_[LT]; SET.v2 = src_[2 * LT]; SET.v3 = src_[3 * LT]; SET.v4 = src_[4 * LT]; SET.v5 = src_[5 * LT]; } while (0)
+#else
+        // weight pieces through a buffer descriptor: one per-thread byte offset (lt * 16) + a compile-time scalar offset per piece,
+        // instead of 64-bit addresses in VGPRs (36 of them, which hipcc hoists out of the tile loop and -- once anything else
+        // needs the registers -- spills; a spill reload waits vmcnt(0), i.e. for every tile request in flight)
+        const auto rs_w = make_rsrc(a.wpk, (size_t)6 * GB);
+        const unsigned lt16 = (unsigned)lt * 16u;
+#define WD_LOAD_B(GRP, K) __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, lt16, (((GRP) % 6) * PG + (K) * LT) * 16, 0))
+#define WD_ISSUE_B(GRP, SET)                                                                                        \
+    do { SET.v0 = WD_LOAD_B(GRP, 0); SET.v1 = WD_LOAD_B(GRP, 1); SET.v2 = WD_LOAD_B(GRP, 2);                          \
+         SET.v3 = WD_LOAD_B(GRP, 3); SET.v4 = WD_LOAD_B(GRP, 4); SET.v5 = WD_LOAD_B(GRP, 5); } while (0)
+#endif
 #define WD_WRITE_B(GRP, SET)                                                                                        \
     do { u32x4* dst_ = reinterpret_cast<u32x4*>(lds_b + ((GRP) & 1) * GB) + lt;                                     \
          dst_[0] = SET.v0; dst_[LT] = SET.v1; dst_[2 * LT] = SET.v2; dst_[3 * LT] = SET.v3; dst_[4 * LT] = SET.v4; dst_[5 * LT] = SET.v5; } while (0)
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-        TileCtr cur = ctr0, nxt = ctr0;
+        TileCtr cur = ctr0, nxt = ctr0, nxt2 = ctr0;    // this tile, the next one, the one after
         nxt.next();
+        nxt2.next(); nxt2.next();
         [[maybe_unused]] int sidx = 0;
         {   // first tile: all four raw planes (its q planes are written in its window, like every column start)
             const Coord c0 = coord_of(cur);
@@ -2220,19 +2235,36 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
             STAMP(wave, sidx, lane);
             MSNET_LDS_BARRIER();                        // b1: the MFMA waves are done with the previous tile (plane 3, both weight buffers)
             STAMP(wave, sidx, lane);
+#ifdef EXP_WD_P2_LATE
             if (!early) { write_q(I0{}, S[P], S[1 - P]); write_q(I1{}, S[P], S[1 - P]); write_q(I2{}, S[P], S[1 - P]); }   // column start
             // the next tile's p2 goes into this tile's p0 registers (dead once q0 is written): requested here already, two and a
             // half groups before its first use; p3 follows behind b2 into the p1 registers, which q3 below still reads
             issue(S[P][0], nx, 2, more);
+#else
+            // column start: its q0..q2 are built here, and the next tile's p2 is requested into this tile's p0 registers (dead once
+            // q0 is written).  For a continuing tile that request went out six slots ago (behind g3 of the previous item).
+            if (!early) {
+                write_q(I0{}, S[P], S[1 - P]); write_q(I1{}, S[P], S[1 - P]); write_q(I2{}, S[P], S[1 - P]);
+                issue(S[P][0], nx, 2, more);
+            }
+#endif
             write_q(I3{}, S[P], S[1 - P]);             // (weight group 0 was copied under the previous tile's last group)
             STAMP(wave, sidx, lane);
             MSNET_LDS_BARRIER();                        // b2: tile and weight group 0 are in LDS
             STAMP(wave, sidx, lane);
             // next tile: its p2, p3 always go into this tile's p0 / p1 registers (dead since the window); a column start also
             // fetches its own p0, p1 into this tile's p2 / p3 registers and builds all its q planes in its window
+#ifdef EXP_WD_P2_LATE
             issue(S[P][1], nx, 3, more);
             if (!ncont) { issue(S[1 - P][0], nx, 0, more); issue(S[1 - P][1], nx, 1, more); }
             WD_WRITE_B(1, bw[0]); WD_ISSUE_B(2, bw[0]);
+#else
+            // (the weight request first: vmcnt counts in order, so the copy of group 2 one slot on must not have to wait for the
+            // plane requests -- HBM -- that would otherwise sit in front of it)
+            WD_WRITE_B(1, bw[0]); WD_ISSUE_B(2, bw[0]);
+            issue(S[P][1], nx, 3, more);
+            if (!ncont) issue(S[1 - P][1], nx, 1, more);            // (a column start's p0 follows behind g3, see there)
+#endif
             STAMP(wave, sidx, lane);
             MSNET_LDS_BARRIER();                        // g0
             STAMP(wave, sidx, lane);
@@ -2251,13 +2283,22 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
             MSNET_LDS_BARRIER();                        // g3
             STAMP(wave, sidx, lane);
             WD_WRITE_B(5, bw[0]); WD_ISSUE_B(6, bw[0]);      // (group 6 = the next tile's group 0)
+#ifndef EXP_WD_P2_LATE
+            // The registers of p2 (= the next tile's p0) are dead since q0' was written behind g1: the p2 of the tile AFTER next goes into
+            // them, six slots before its first use (q0'' behind the next g1) instead of two and a half -- the
+            // q writes no longer wait for HBM.  At a column start (no q0' here) the same request fetches the next tile's p0.
+            {
+                const Coord nx2 = coord_of(ncont ? nxt2 : nxt);
+                issue(S[1 - P][0], nx2, ncont ? 2 : 0, ncont ? it + 2 < nitems : more);
+            }
+#endif
             STAMP(wave, sidx, lane);
             MSNET_LDS_BARRIER();                        // g4: taps ..29 done, q2 is dead
             STAMP(wave, sidx, lane);
             if (ncont) write_q(I2{}, S[1 - P], S[P]);
             WD_WRITE_B(6, bw[0]); WD_ISSUE_B(7, bw[0]);      // the next tile's group 0 into buffer 0 (free since g4), its group 1 requested
             early = ncont;
-            cur = nxt; nxt.next();
+            cur = nxt; nxt.next(); nxt2.next();
         };
         for (int it = 0; it < nitems; it += 2) {
             item(I0{}, it);
