@@ -476,6 +476,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #endif
 #ifndef EXP_NO_GROUP_BARRIER
 // slot of group G: copy group G + BA (BA = 2 with three LDS buffers, else 1) and request the group NSETS later into the freed set
+#ifdef EXP_B_LAST
+#define MSNET_GROUP_FIRST(PAR)
 #define MSNET_GROUP(G, PAR)                                                         \
     MSNET_WRITE_B(k0 + (G) + BA, bw[MSNET_SETI((G) + BA, PAR)]);                    \
     MSNET_ISSUE_B((G) + BA + NSETS, bw[MSNET_SETI((G) + BA, PAR)]);                 \
@@ -483,6 +485,21 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     MSNET_LDS_BARRIER();                                                            \
     STAMP(wave, sidx, lane);
 #else
+// The weight copy + request of a slot come FIRST in it (right behind the barrier that opens it), the tile requests and plane copies
+// behind them: vmcnt counts in order, so a weight copy NSETS slots on then waits for tile requests up to the slot BEFORE its own
+// request, not including that slot's (HBM) requests.
+#define MSNET_GROUP_B(G, PAR)                                                       \
+    MSNET_WRITE_B(k0 + (G) + BA, bw[MSNET_SETI((G) + BA, PAR)]);                    \
+    MSNET_ISSUE_B((G) + BA + NSETS, bw[MSNET_SETI((G) + BA, PAR)]);
+#define MSNET_GROUP_FIRST(PAR) MSNET_GROUP_B(0, PAR)
+#define MSNET_GROUP(G, PAR)                                                         \
+    STAMP(wave, sidx, lane);                                                        \
+    MSNET_LDS_BARRIER();                                                            \
+    STAMP(wave, sidx, lane);                                                        \
+    if constexpr ((G) < 7) { MSNET_GROUP_B((G) + 1, PAR) }
+#endif
+#else
+#define MSNET_GROUP_FIRST(PAR)
 #define MSNET_GROUP(G, PAR)                                                         \
     MSNET_WRITE_B(k0 + (G) + BA, bw[MSNET_SETI((G) + BA, PAR)]);                    \
     MSNET_ISSUE_B((G) + BA + NSETS, bw[MSNET_SETI((G) + BA, PAR)]);
@@ -571,6 +588,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 STAMP(wave, sidx, lane);
                 MSNET_LDS_BARRIER();                    // b2: tile and group 0 are in LDS
                 STAMP(wave, sidx, lane);
+                MSNET_GROUP_FIRST(0)
                 issue_a(av[0], nx, p0, more, 0, PL); issue_a(av[1], nx, p0 + 1, more, 0, HH);
                 MSNET_GROUP(0, 0)
                 issue_a(av[1], nx, p0 + 1, more, HH, PL); issue_a(av[2], nx, 2, more && !ncont, 0, PL);
@@ -617,6 +635,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             STAMP(wave, sidx, lane);
             MSNET_LDS_BARRIER();                        // b2: tile and group 0 are in LDS
             STAMP(wave, sidx, lane);
+            MSNET_GROUP_FIRST(PAR)
             // group g+1 is copied to LDS (and group g+4 requested) while group g is multiplied; barrier g_g ends it.
             // The next tile is requested during groups 0-2; its planes 0 / 1 are copied as soon as they are dead.  (Past the
             // last item the requests are dead -- `more` = false -- and the copies put zeros into planes nobody reads again.)
@@ -701,6 +720,10 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             }
         }
 #undef MSNET_GROUP
+#undef MSNET_GROUP_FIRST
+#ifdef MSNET_GROUP_B
+#undef MSNET_GROUP_B
+#endif
 #undef MSNET_WINDOW_B
 #undef MSNET_TAIL_B
 #undef MSNET_WRITE_B
@@ -2120,7 +2143,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
     const int my_units = (T > lb) ? (int)((T - lb + G - 1) / G) : 0;
     const int nitems = my_units * a.seglen;
     if (nitems == 0) return;
-    const u32x4* wg = reinterpret_cast<const u32x4*>(a.wpk);
+    [[maybe_unused]] const u32x4* wg = reinterpret_cast<const u32x4*>(a.wpk);     // (-DEXP_WD_GLOBAL_B only)
     TileCtr ctr0;
     ctr0.init(lb, G, 1, a.ntw, a.nth, a.nseg, a.seglen);
     struct Coord { int n, od0, oh0, ow0; };
