@@ -65,6 +65,85 @@ def gcnet_flops(H, W, D):
     return 2.0 * mac
 
 
+def psmnet_flops(H, W, D):
+    """Algorithmic FLOPs of the PSMNet aggregator's 28 convs per map (505 GMAC at cfg#3)."""
+    v0 = (D // 4) * (H // 4) * (W // 4)
+    mac = 27 * v0 * (64 * 32 + 3 * 32 * 32)                                      # dres0, dres1
+    mac += 3 * 27 * v0 * (32 * 64 // 8 + 64 * 64 // 8 + 3 * 64 * 64 // 64 + 64 * 32 // 8)      # three hourglasses
+    mac += 3 * 27 * v0 * (32 * 32 + 32)                                          # three classification heads
+    return 2.0 * mac
+
+
+class PowerSampler:
+    """Package power and shader clock DURING the timed region, read from the amdgpu hwmon / sysfs files of the device by a side
+    thread (plain file reads -- no HIP call, no rocm-smi process): the headline is power-limited, so the line says
+    at how many watts and at which granted clock it was measured.  Every field is None where the box does not expose the file."""
+
+    def __init__(self, index=0, period_s=0.004):
+        import glob
+        self.period, self.samples, self._stop, self._thr = period_s, [], False, None
+        self.power_file = self.sclk_file = None
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
+        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/power1_*"))]
+        if index < len(cards):
+            c = cards[index]
+            for name in ("power1_average", "power1_input"):
+                f = glob.glob(os.path.join(c, "hwmon/hwmon*/" + name))
+                if f:
+                    self.power_file = f[0]
+                    break
+            f = glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input"))
+            self.sclk_file = f[0] if f else None
+            self.dpm_file = os.path.join(c, "pp_dpm_sclk")
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return f.read()
+        except Exception:
+            return None
+
+    def _sample(self):
+        w = mhz = None
+        t = self._read(self.power_file) if self.power_file else None
+        if t:
+            w = float(t) * 1e-6                                   # microwatts
+        t = self._read(self.sclk_file) if self.sclk_file else None
+        if t:
+            mhz = float(t) * 1e-6                                 # Hz
+        elif getattr(self, "dpm_file", None):
+            t = self._read(self.dpm_file)
+            for ln in (t or "").splitlines():
+                if ln.rstrip().endswith("*"):
+                    mhz = float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        return w, mhz
+
+    def start(self):
+        import threading
+        if not (self.power_file or self.sclk_file):
+            return self
+
+        def loop():
+            while not self._stop:
+                self.samples.append(self._sample())
+                time.sleep(self.period)
+        self._thr = threading.Thread(target=loop, daemon=True)
+        self._thr.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._thr is not None:
+            self._thr.join(1.0)
+        ws = [w for w, _ in self.samples if w]
+        ms = [m for _, m in self.samples if m]
+        return {"power_w": float(np.mean(ws)) if ws else None, "power_w_max": float(np.max(ws)) if ws else None,
+                "sclk_mhz": float(np.mean(ms)) if ms else None, "samples": len(self.samples),
+                "source": ("amdgpu hwmon sysfs, side thread, every %.0f ms of the timed region" % (1e3 * self.period)
+                           if self.samples else "not exposed on this box")}
+
+
 def _source_sha(*names):
     h = hashlib.sha256()
     for n in names:
@@ -193,24 +272,53 @@ def measure_peaks(dev):
 def self_launch(n):
     """`python bench.py --gpus N` without an external launcher: this process -- which has made NO GPU / HIP call yet and never
     does -- starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a CHILD process (it is never
-    replaced by another program), relays the child's output (rank 0's JSON line on stdout) and returns its exit code."""
+    replaced by another program), relays the child's output (rank 0's JSON line on stdout) and returns its exit code.  The
+    child runs in its own process group; if this process is interrupted or terminated the whole group is, so no rank is left
+    holding a GPU."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as so:
         so.bind(("127.0.0.1", 0))
         port = so.getsockname()[1]
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MSNET_BENCH_SELF_LAUNCHED="1")
+    env = dict(os.environ, MSNET_BENCH_SELF_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this pool (a user's own value wins)
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(1, n))))
     argv = [a for a in sys.argv[1:] if a != "--self-launch"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + argv
     # rank 0's JSON line goes to stdout alone; anything else the ranks or RCCL print on stdout (RCCL's version banner) is relayed
     # on stderr, so that `python bench.py --gpus N` prints ONE line on stdout as the single-process run does
-    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
-    for ln in proc.stdout:
-        (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
-        sys.stdout.flush()
-    return proc.wait()
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)
+
+    def stop_child(sig=signal.SIGTERM):
+        if proc.poll() is None:
+            try:
+                os.killpg(proc.pid, sig)               # the group this Popen created (start_new_session): launcher + ranks, nothing else
+            except ProcessLookupError:
+                pass
+
+    def on_signal(signum, frame):
+        stop_child(signum)
+        raise KeyboardInterrupt
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    try:
+        for ln in proc.stdout:
+            (sys.stdout if ln.lstrip().startswith("{") else sys.stderr).write(ln)
+            sys.stdout.flush()
+        return proc.wait()
+    except (KeyboardInterrupt, BrokenPipeError):
+        return 130
+    finally:
+        for sg, h in old.items():
+            signal.signal(sg, h)
+        if proc.poll() is None:
+            stop_child()
+            try:
+                proc.wait(10)
+            except subprocess.TimeoutExpired:
+                stop_child(signal.SIGKILL)
+                proc.wait()
 
 
 def main():
@@ -220,25 +328,42 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--batch-per-gpu", type=int, default=1)
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="total pairs per step over all ranks (default: --batch-per-gpu x world); a value that is not a multiple "
+                         "of the world size gives the ranks uneven shares (sample i -> rank i mod world) -- diagnostic")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the fp32_exact loop and the peak micro-benchmarks")
     ap.add_argument("--no-volume", action="store_true", help="aggregator only (random volume), not the headline")
+    ap.add_argument("--volume-layout", default="ndhwc", choices=["ndhwc", "ncdhw"],
+                    help="layout of the volume handed from the build to the aggregator: 'ndhwc' (default) = the kernels' own "
+                         "channels-last layout (VolumeBuilder(layout='ndhwc') + forward_ndhwc: no layout pass); 'ncdhw' = the "
+                         "reference's layout through the drop-in forward() (one 802 MB conversion pass per map)")
     ap.add_argument("--precision", default="split-fp16", choices=["split-fp16", "fp32"])
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-launch HIP events (diagnostic)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the aggregator forward from a captured HIP graph (module.use_graph); its launches then carry no "
                          "HIP events, so the roofline of the dominant kernel is not measured in such a run -- diagnostic, not the default")
+    ap.add_argument("--dist-backend", default=None, choices=["nccl", "gloo"],
+                    help="torch.distributed backend (default: RCCL = 'nccl'; env MSNET_DIST_BACKEND).  'gloo' lets several ranks share "
+                         "one GPU (LOCAL_RANK modulo the device count, collective through host memory): a functional run of the "
+                         "world > 1 path on a 1-GPU box, not a measurement")
     ap.add_argument("--self-launch", action="store_true",
                     help="start the ranks as a child `python -m torch.distributed.run` even for --gpus 1 (what --gpus N>1 does by "
                          "itself when no launcher set RANK)")
     args = ap.parse_args()
 
+    if args.dist_backend:
+        os.environ["MSNET_DIST_BACKEND"] = args.dist_backend
     if (args.gpus > 1 or args.self_launch) and "RANK" not in os.environ:
         raise SystemExit(self_launch(args.gpus))
 
     import msnets_amd
-    from msnets_amd import _lib, cbmv_generator, dist as msdist, hipops, synthetic
+    from msnets_amd import dist as msdist
+    numa_node = None
+    if "RANK" in os.environ:        # one process per GPU: keep the launch thread on the GPU's socket (sysfs only, no GPU call yet)
+        numa_node = msdist.bind_to_gpu_numa_node(int(os.environ.get("LOCAL_RANK", "0")))
+    from msnets_amd import _lib, cbmv_generator, hipops, synthetic
     from msnets_amd.gcnet_3dcnn import GCNet_CostVolumeAggre
 
     rank, world, local = msdist.init_from_env()
@@ -253,8 +378,10 @@ def main():
 
     H, W, D, desc = WORKLOADS[args.workload]
     hh, wh, nd = H // 2, W // 2, D // 2
-    B = args.batch_per_gpu
-    n_total = B * world
+    n_total = args.global_batch or args.batch_per_gpu * world
+    if n_total < world:
+        raise SystemExit("--global-batch %d < world size %d" % (n_total, world))
+    B = len(msdist.shard_indices(n_total, rank, world))        # this rank's pairs per step (rank 0 holds the largest share)
 
     # synthetic inputs, resident in HBM before the timed region; sample i -> rank i % world
     pairs = []
@@ -267,10 +394,12 @@ def main():
         model = PSMNet_CostVolumeAggre(D).eval().to(dev)
         vol = synthetic.random_volume((B, 64, D // 4, H // 4, W // 4), seed=rank).to(dev)
         args.no_volume = True
+        cl = False
     else:
         model = GCNet_CostVolumeAggre(D).eval().to(dev)
-        builder = cbmv_generator.VolumeBuilder(hh + 20, wh + 20, nd, dev)
-        vol = torch.empty((B, 8, nd, hh, wh), device=dev, dtype=torch.float32)
+        cl = args.volume_layout == "ndhwc" and not args.no_volume
+        builder = cbmv_generator.VolumeBuilder(hh + 20, wh + 20, nd, dev, layout="ndhwc" if cl else "ncdhw")
+        vol = torch.empty((B,) + builder.out_shape, device=dev, dtype=torch.float32)
         if args.no_volume:
             vol.copy_(synthetic.random_volume(tuple(vol.shape), seed=rank).to(dev))
 
@@ -280,7 +409,7 @@ def main():
         if not args.no_volume:
             for b, (l, r) in enumerate(pairs):
                 builder(l, r, out=vol[b])
-        return model(vol)
+        return model.forward_ndhwc(vol) if cl else model(vol)
 
     def step():
         return msdist.gather_disparities(local_step(), n_total)
@@ -308,17 +437,20 @@ def main():
     torch.cuda.synchronize()
     assert out.shape == (n_total, H, W) and bool(torch.isfinite(out).all())
 
-    # HIP events around the launches of the dominant kernel family and the volume-build kernels only (all families with
-    # --verbose): the two event records per launch cost host time, 0.18 ms per step (2 %) when all ~45 launches are timed.
-    # conv3dbn_2 (32->32 at full half-res, once per map): the Winograd-depth launch ("conv3d_s1_wd_f16s") where it is taken,
-    # else the direct split-fp16 kernel ("conv3d_s1_f16s_co32")
-    dom_families = (("conv3d_s1_wd_f16s", "conv3d_s1_f16s_co32") if args.precision != "fp32" and args.workload != "cfg3"
-                    else ("conv3d_s1",))
-    dom_prefix = None if args.verbose else ",".join(dom_families + VOLUME_FAMILIES)
+    # HIP events inside the timed region: around the launches of the stride-1 conv families (one of them is the step's largest
+    # family by total time in every workload) and the volume build only -- the two event records per launch cost 0.18 ms per
+    # step (2 %) when all ~45 launches are timed.  Every family is timed in an untimed POST-PASS of three more steps
+    # (`roofline.kernels`), which is also what names the dominant family; --verbose times every family inside the timed region.
+    f16path = args.precision != "fp32"
+    timed_families = ("conv3d_s1_wd_f16s", "conv3d_s1_f16s_co") if f16path else ("conv3d_s1",)
+    dom_prefix = None if args.verbose else ",".join(timed_families + VOLUME_FAMILIES)
     _lib.prof_enable(not args.no_kernel_timing, dom_prefix)
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    sampler = PowerSampler(local)
     msdist.barrier()
     torch.cuda.synchronize()
+    if rank == 0:
+        sampler.start()
     t0 = time.perf_counter()
     step_ev[0].record()
     for k in range(args.steps):
@@ -327,45 +459,87 @@ def main():
     torch.cuda.synchronize()
     msdist.barrier()
     dt = time.perf_counter() - t0
+    power = sampler.stop() if rank == 0 else None
     _lib.prof_enable(False)
     prof = _lib.prof_collect()
     all_timed = dom_prefix is None and not args.no_kernel_timing
     per_step = sorted(step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps))
+    guard_tripped = model._forced_precision is not None           # the fp16-range guard moved the module to fp32 (hipops)
 
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if msdist.backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+
+    # post-pass (untimed, every rank: a step contains the collective): all families under HIP events
+    POST_STEPS = 3
+    if all_timed:
+        prof_all, post_steps = prof, args.steps
+    elif args.no_kernel_timing:
+        prof_all, post_steps = {}, 0
+    else:
+        _lib.prof_enable(True, None)
+        for _ in range(POST_STEPS):
+            step()
+        torch.cuda.synchronize()
+        _lib.prof_enable(False)
+        prof_all, post_steps = _lib.prof_collect(), POST_STEPS
+
+    def family_row(name, v, steps, src):
+        """One kernel family against the roofline that bounds it.  MFMA families: algorithmic (direct-conv) FLOPs / time vs
+        2500 / executed fp16 MFMAs per algorithmic product (3 split-fp16; 2 in the Winograd-depth kernel: 3 x 2/3), or vs the
+        fp32-input MFMA peak; HBM families: algorithmic bytes / time vs 8 TB/s."""
+        ms = v["ms"]
+        row = {"family": name, "ms_per_step": ms / max(1, steps), "launches_per_step": v["calls"] / max(1, steps), "timed_in": src}
+        conv = name.startswith(("conv3d_s", "deconv3d")) and v["flops"] > 0
+        if conv:
+            mf = (2.0 if name == "conv3d_s1_wd_f16s" else 3.0) if "f16s" in name else None
+            peak = FP16_MATRIX_PEAK_TFLOPS / mf if mf else FP32_MATRIX_PEAK_TFLOPS
+            ach = v["flops"] / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            row.update(bound="mfma", achieved=ach, peak=peak, unit="TFLOP/s", frac=ach / peak, mfmas_per_algorithmic_product=mf)
+        else:
+            ach = v["bytes"] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            row.update(bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS)
+        return row
 
     if rank == 0:
         maps = n_total * args.steps
         pct = lambda q: float(np.percentile(per_step, q))      # noqa: E731
-        # dominant kernel = the stride-1 conv3d family: split-fp16 MFMA when that precision is active, else fp32 MFMA
-        f16 = {k: v for k, v in prof.items() if k.startswith(("conv3d_s1_f16s", "conv3d_s1_wd_f16s"))}
-        dom_family = dom_families[0]
-        if f16:
-            # the single largest launch: conv3dbn_2 (32->32 at full half-res), once per map
-            key = next((k for k in ("conv3d_s1_wd_f16s", "conv3d_s1_f16s_co32") if k in f16), None) or max(f16, key=lambda k: f16[k]["ms"])
-            dom_family, dom = key, f16[key]
-            if key == "conv3d_s1_wd_f16s":
-                # Winograd F(2,3) along depth: 4 transformed planes per 2 output planes x 9 in-plane taps = 18 instead of 27
-                # products per output voxel, each still 3 fp16 MFMAs -> 2 executed MFMAs per ALGORITHMIC (direct-conv) product
-                mfmas = SPLIT_MFMAS_PER_PRODUCT * 2.0 / 3.0
-                dom_name = "conv3d_wd_f16s_kernel / %s (Winograd F(2,3) along depth, split-fp16 MFMA: 2 MFMAs per algorithmic product)" % key
-                peak_note = ("fp16 dense MFMA peak 2500 TFLOP/s / 2 executed MFMAs per algorithmic product (3 split-fp16 MFMAs x 2/3 "
-                             "Winograd); `achieved` counts the direct convolution's FLOPs")
-            else:
-                mfmas = SPLIT_MFMAS_PER_PRODUCT
-                dom_name = "conv3d_k3s1_f16s_ws / %s (split-fp16 MFMA, 3 MFMAs per product)" % key
-                peak_note = "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product"
-            peak = FP16_MATRIX_PEAK_TFLOPS / mfmas
-        else:
-            dom_name, dom = "conv3d_k3_mfma_ws (fp32-input MFMA, stride-1 launches)", prof.get(
-                "conv3d_s1", {"ms": 0.0, "flops": 0.0, "calls": 0})
-            peak, peak_note, mfmas = FP32_MATRIX_PEAK_TFLOPS, "fp32-input MFMA peak", None
+        # every family of the step, largest first ("volk_*" are the kernels inside "vol_build": not counted twice)
+        fam = {k: v for k, v in prof_all.items() if not k.startswith("volk_") and v["ms"] > 0}
+        tot_ms = sum(v["ms"] for v in fam.values())
+        ranked = sorted(fam, key=lambda k: -fam[k]["ms"])
+        kernels = []
+        for k in ranked[:3]:
+            # a family timed inside the timed region is quoted from there, the others from the post-pass
+            row = family_row(k, prof[k], args.steps, "timed region") if k in prof else family_row(k, fam[k], post_steps, "post-pass")
+            row["time_share_of_kernels"] = fam[k]["ms"] / tot_ms
+            kernels.append(row)
+        # dominant = the family with the largest TOTAL time (profiles/*_kernel_stats.csv row 1 names the same kernel)
+        if kernels:
+            top = kernels[0]
+            dom_family = top["family"]
+            dom = prof[dom_family] if dom_family in prof else fam[dom_family]
+            dom_steps = args.steps if dom_family in prof else post_steps
+        else:           # --no-kernel-timing
+            dom_family, dom, dom_steps, top = "none", {"ms": 0.0, "flops": 0.0, "calls": 0, "bytes": 0.0}, 1, None
+        DESCR = {
+            "conv3d_s1_wd_f16s": ("conv3d_wd_f16s_kernel (32->32 stride-1 layers, Winograd F(2,3) along depth, split-fp16 MFMA: 2 MFMAs per "
+                                  "algorithmic product)", "fp16 dense MFMA peak 2500 TFLOP/s / 2 executed MFMAs per algorithmic product (3 "
+                                  "split-fp16 MFMAs x 2/3 Winograd); `achieved` counts the direct convolution's FLOPs"),
+            "conv3d_s1_f16s_co64": ("conv3d_k3s1_f16s_ws, Co = 64 instantiations (the 64->64 stride-1 layers of the encoder; split-fp16 MFMA, "
+                                    "3 MFMAs per product)", "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product"),
+            "conv3d_s1_f16s_co32": ("conv3d_k3s1_f16s_ws, Co = 32 (direct split-fp16 MFMA, 3 MFMAs per product)",
+                                    "fp16 dense MFMA peak 2500 TFLOP/s / 3 MFMAs per algorithmic product"),
+            "conv3d_s1": ("conv3d_k3_mfma_ws (fp32-input MFMA, stride-1 launches)", "fp32-input MFMA peak"),
+        }
+        dom_name, peak_note = DESCR.get(dom_family, (dom_family, "see roofline.kernels"))
+        mfmas = top.get("mfmas_per_algorithmic_product") if top else None
+        peak = top["peak"] if top and top["bound"] == "mfma" else (FP16_MATRIX_PEAK_TFLOPS / SPLIT_MFMAS_PER_PRODUCT if f16path
+                                                                    else FP32_MATRIX_PEAK_TFLOPS)
         achieved = dom["flops"] / (dom["ms"] * 1e-3) / 1e12 if dom["ms"] > 0 else 0.0
-        conv_ms = sum(v["ms"] for k, v in prof.items() if k.startswith(("conv3d", "deconv3d")))
-        conv_fl = sum(v["flops"] for k, v in prof.items() if k.startswith(("conv3d", "deconv3d")))
+        conv_ms = sum(v["ms"] for k, v in prof_all.items() if k.startswith(("conv3d", "deconv3d")))
+        conv_fl = sum(v["flops"] for k, v in prof_all.items() if k.startswith(("conv3d", "deconv3d")))
         line = {
             "metric": "disparity maps/sec, 960x540 D=192 MS-GCNet fwd" if args.workload == "cfg2" else
                       "disparity maps/sec (%s, not the headline)" % args.workload,
@@ -374,68 +548,92 @@ def main():
             "dtype": "f32" if args.precision == "fp32" else "f32 (conv operands as split fp16 hi+lo, fp32 accumulate)",
             "data": "synthetic",
             "config": {"workload": desc + ", batch=%d per GPU" % B, "global_batch": n_total,
-                       "parallelism": "dp%d (rank-sharded pairs, RCCL all-gather of disparity maps)" % world,
+                       "parallelism": "dp%d (rank-sharded pairs, %s all-gather of disparity maps)" % (world, msdist.backend() or "no"),
                        "includes_volume_build": not args.no_volume, "hip_graph": bool(args.graph),
-                       "collective": ("rccl all_gather_into_tensor" if torch.distributed.is_available() and
-                                      torch.distributed.is_initialized() else "none (single process)"),
-                       "world_size": (torch.distributed.get_world_size() if torch.distributed.is_available() and
-                                      torch.distributed.is_initialized() else 1),
-                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if torch.distributed.is_available()
-                                        and torch.distributed.is_initialized() else None),
+                       "volume_layout": ("ndhwc (channels-last hand-over, no layout pass)" if cl else
+                                         "ncdhw (the reference's layout, one conversion pass)"),
+                       "collective": ("%s all_gather_into_tensor" % ("rccl" if msdist.backend() == "nccl" else msdist.backend())
+                                      if msdist.backend() else "none (single process)"),
+                       "world_size": (torch.distributed.get_world_size() if msdist.backend() else 1),
+                       "dist_backend": msdist.backend(),
+                       "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if msdist.backend() == "nccl" else None),
+                       "ranks_per_device": msdist.ranks_per_device(),
+                       "numa_node_bound": numa_node,
                        "launcher": ("bench.py self-launch (child torch.distributed.run)" if os.environ.get("MSNET_BENCH_SELF_LAUNCHED")
-                                    else "torch.distributed.run" if "RANK" in os.environ else "single process")},
+                                    else "torch.distributed.run" if "RANK" in os.environ else "single process"),
+                       # what the headline depends on besides the code (the step is power-limited, so identical
+                       # instruction streams run 5 % apart on different data and 3 % apart on different boxes)
+                       "weights": "net_init (seeded random), BatchNorm at its identity defaults -- no trained checkpoint exists offline",
+                       "range_guard_tripped": bool(guard_tripped)},
+            "power": power,
             "step_ms": {"median": pct(50), "p10": pct(10), "p90": pct(90), "source": "HIP events between steps, rank 0"},
-            "roofline": {"bound": "mfma", "kernel": dom_name, "achieved": achieved,
+            "roofline": {"bound": "mfma", "kernel": dom_name, "family": dom_family,
+                         "dominant_by": "largest total kernel time per step (all families under HIP events, %s)" % (
+                             "timed region" if all_timed else "post-pass of %d untimed steps" % post_steps),
+                         "achieved": achieved,
                          "peak": peak, "peak_note": peak_note, "unit": "TFLOP/s", "frac": achieved / peak,
-                         # rounds 1-2 quoted the direct split-fp16 ceiling 2500/3 for this layer; kept for comparison only
+                         "timed_in": top["timed_in"] if top else None,
+                         # rounds 1-2 quoted the direct split-fp16 ceiling 2500/3; kept for comparison only
                          "frac_of_direct_split_peak": (achieved / (FP16_MATRIX_PEAK_TFLOPS / SPLIT_MFMAS_PER_PRODUCT)
                                                        if mfmas else None),
                          "mfmas_per_algorithmic_product": mfmas,
-                         "time_share_of_step": dom["ms"] / (1e3 * dt) if dt > 0 else 0.0,
+                         "time_share_of_step": dom["ms"] / dom_steps / (1e3 * dt / args.steps) if dt > 0 else 0.0,
                          "launches": dom["calls"], "avg_launch_ms": dom["ms"] / max(1, dom["calls"]),
-                         "all_conv_tflops": (conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0) if all_timed else None,
+                         "all_conv_tflops": (conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else None),
+                         "kernels": kernels,
                          "traffic": pmc_traffic(dom_family, args.workload, B)},
         }
         facts = profile_facts(args.workload, B)
         if facts:
-            # the tracked rocprofv3 --kernel-trace --stats run of this very source: average duration of the dominant kernel
+            # the tracked rocprofv3 --kernel-trace --stats run of this very source: average duration of the dominant family's launches
             ns = facts.get("kernel_avg_ns", {}).get(dom_family)
             if ns and dom["calls"]:
                 fl = dom["flops"] / dom["calls"]
                 line["roofline"]["avg_launch_ms_rocprof"] = ns * 1e-6
                 line["roofline"]["frac_rocprof"] = fl / (ns * 1e-9) / 1e12 / peak
+            else:
+                line["roofline"].update(avg_launch_ms_rocprof=None, frac_rocprof=None)
             line["roofline"]["sustained_clock_ghz"] = facts.get("sustained_clock_ghz", {}).get(dom_family)
             line["roofline"]["profile_facts"] = os.path.relpath(FACTS_FILE, ROOT)
         else:
             line["roofline"].update(avg_launch_ms_rocprof=None, frac_rocprof=None, sustained_clock_ghz=None,
                                     profile_facts="none for this kernel source (profiles/ holds an older build's)")
-        if args.workload != "cfg3" and args.precision != "fp32":
-            # whole-step MFMA roofline without per-launch events: the 19 convs' algorithmic FLOPs per map / the step time
-            # (volume build, layout conversion, tail and all gaps included) vs the same peak as `roofline`
-            fl_map = gcnet_flops(H, W, D)
+        if f16path and (prof_all or args.workload != "cfg3"):
+            # whole-step MFMA roofline: the convs' algorithmic FLOPs per map / the step time (volume build, layout conversion,
+            # tail and all gaps included).  Executed fp16 MFMAs per algorithmic product over the whole map: 3 everywhere, 2 in
+            # the Winograd-depth launches, whose FLOPs PER MAP come from the events (a launch covers the B maps of the batch).
+            fl_map = psmnet_flops(H, W, D) if args.workload == "cfg3" else gcnet_flops(H, W, D)
             step_tf = fl_map * n_total / world / (1e-3 * 1e3 * dt / args.steps) / 1e12
-            # executed fp16 MFMAs per algorithmic product over the whole map: 3 everywhere, 2 in the Winograd-depth launches
-            wd_fl = prof.get("conv3d_s1_wd_f16s", {"flops": 0.0, "calls": 0})
-            wd_fl_map = wd_fl["flops"] / max(1, wd_fl["calls"]) if wd_fl["calls"] else (
-                2.0 * 27 * 32 * 32 * nd * hh * wh if dom_family == "conv3d_s1_wd_f16s" else 0.0)
+            wd_src, wd_steps = (prof, args.steps) if "conv3d_s1_wd_f16s" in prof else (prof_all, post_steps)
+            wd_fl = wd_src.get("conv3d_s1_wd_f16s", {"flops": 0.0})
+            wd_fl_map = wd_fl["flops"] / (max(1, wd_steps) * B)
+            if not prof_all and args.workload != "cfg3" and hipops.USE_WINOGRAD_DEPTH and \
+                    _lib.load().msnet_conv3d_k3_wd_f16s_supported(nd, hh, wh, 32, 32, 1):
+                wd_fl_map = 2.0 * 27 * 32 * 32 * nd * hh * wh           # no events at all (--no-kernel-timing): conv3dbn_2, analytically
             step_mfmas = SPLIT_MFMAS_PER_PRODUCT - wd_fl_map / fl_map
             step_peak = FP16_MATRIX_PEAK_TFLOPS / step_mfmas
             line["roofline_step"] = {"bound": "mfma", "achieved": step_tf, "peak": step_peak, "unit": "TFLOP/s",
                                      "frac": step_tf / step_peak,
                                      "frac_of_direct_split_peak": step_tf / (FP16_MATRIX_PEAK_TFLOPS / SPLIT_MFMAS_PER_PRODUCT),
                                      "mfmas_per_algorithmic_product": step_mfmas, "flops_per_map": fl_map,
+                                     "winograd_flops_per_map": wd_fl_map,
                                      "note": "per GPU: algorithmic (direct-conv) FLOPs of the maps one rank processes per step / "
                                              "wall time per step; peak = 2500 TFLOP/s fp16 dense / executed MFMAs per algorithmic "
-                                             "product averaged over the 19 convs (3, or 2 in the Winograd-depth launch)"}
+                                             "product averaged over the convs (3, or 2 in the Winograd-depth launches)"}
         volk = {k: v for k, v in prof.items() if k.startswith(VOLUME_FAMILIES)}
         if volk and not args.no_volume:
             vms = sum(v["ms"] for v in volk.values())
             alg_bytes = 4.0 * 8 * nd * hh * wh + 2.0 * (hh + 20) * (wh + 20)        # 401.4 MB at cfg#2
             builds = maps / world
             gbs = alg_bytes * builds / (vms * 1e-3) / 1e9 if vms > 0 else 0.0
+            # SURVEY 8(d) prices the build against HBM (its algorithmic bytes / time vs 8 TB/s: `achieved`, `frac`); what LIMITS it
+            # is what the tracked counter pass of this very source says (profiles/*_profile_facts.json: "volume_limiter"), null
+            # when profiles/ holds no pass of this source
+            vfacts = (facts or {}).get("volume_limiter")
             line["roofline_volume"] = {
-                "bound": "hbm", "kernel": "msnet_build_volume: " + " + ".join(sorted(volk)), "achieved": gbs, "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_map": alg_bytes,
+                "bound": (vfacts or {}).get("bound", "hbm"), "priced_against": "hbm", "limiter": vfacts,
+                "kernel": "msnet_build_volume: " + " + ".join(sorted(volk)), "achieved": gbs, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "hbm_frac": gbs / HBM_PEAK_GBS, "algorithmic_bytes_per_map": alg_bytes,
                 "us_per_map": 1e3 * vms / builds,
                 "us_per_map_by_kernel": {k: 1e3 * v["ms"] / builds for k, v in sorted(volk.items())},
                 "traffic": pmc_traffic("volume_build", args.workload, B)}

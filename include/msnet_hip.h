@@ -119,6 +119,15 @@ int    msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, int Wb, in
                           const msnet_volume_params* p_host, void* workspace, float* out,
                           msnet_stream_t stream);
 size_t msnet_build_volume_workspace_bytes(int Hb, int Wb, int ndisp);
+/* The same volume written channels-last, out: f32[D'][H'][W'][8] (channel order unchanged: cbmv_generator.py:283-287,
+ * 301-304) -- the aggregator kernels' own input layout, so GCNet_CostVolumeAggre.forward_ndhwc needs no layout pass between
+ * the build and its first conv (msnet_conv3d_k3_c8_in_f16s).  Bit-identical to msnet_build_volume followed by
+ * msnet_ncdhw_to_ndhwc.  Built for the reference's own parameters only (windows 11/3/5/5, cbmv_generator.py:434-462;
+ * borders >= 6; D' % 8 == 0, D' <= 96): msnet_build_volume_ndhwc_supported() says whether a shape is taken.  Same workspace. */
+int    msnet_build_volume_ndhwc_supported(int Hb, int Wb, int ndisp, const msnet_volume_params* p_host);
+int    msnet_build_volume_ndhwc(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int ndisp,
+                                const msnet_volume_params* p_host, void* workspace, float* out,
+                                msnet_stream_t stream);
 
 /* ---- test-time pre-processing: src/dataloader/cbmv_generator.py:780-788 (pad top/right to a multiple of
  *      encoder_ds), :465-482 (down_sampling_input = skimage rescale by 1/ds with anti-aliasing, x255 -> uint8), :819-823
@@ -189,6 +198,11 @@ int msnet_conv3d_k3_wd_f16s(const float* x, const void* wpk_wd, const float* sca
  * copied.  wpk_f16s as for msnet_conv3d_k3_f16s (Ci = 8).  Out-of-range INPUT values raise bit 1 of the overflow word. */
 int msnet_conv3d_k3_c8_ncdhw_f16s(const float* x_ncdhw, const void* wpk_f16s, const float* scale, const float* shift,
                                   float* y, int N, int D, int H, int W, int Co, int relu, msnet_stream_t stream);
+/* The same first layer on a channels-last module input x: f32[N][D][H][W][8] (what msnet_build_volume_ndhwc writes) ->
+ * y: NDHWC f32[N][D][H][W][Co].  msnet_conv3d_k3_f16s with Ci = 8 plus the range check of the module INPUT (bit 1 of the
+ * overflow word), which the layout-conversion pass carries on the NCDHW route.  Entry of GCNet_CostVolumeAggre.forward_ndhwc. */
+int msnet_conv3d_k3_c8_in_f16s(const float* x_ndhwc, const void* wpk_f16s, const float* scale, const float* shift,
+                               float* y, int N, int D, int H, int W, int Co, int relu, msnet_stream_t stream);
 /* Conv3d(Ci->1, k3, p1, bias=False) head (psmnet_3dcnn.py:112-122 classif*.2), optional "+ add"
  * (cost2 = classif2(out2) + cost1, :146-147).  x: NDHWC; w: f32[1][Ci][3][3][3]; y/add: f32[N][D][H][W].
  * y = wscale * conv(x, w) (+ add): the caller may hand over the weights multiplied by a power of two (so that their fp16

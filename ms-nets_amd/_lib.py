@@ -45,6 +45,8 @@ SIGNATURES = {
     "msnet_volume_default_params": (None, [ctypes.POINTER(VolumeParams)]),
     "msnet_build_volume": (c_int, [P, P, c_int, c_int, c_int, ctypes.POINTER(VolumeParams), P, P, P]),
     "msnet_build_volume_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "msnet_build_volume_ndhwc_supported": (c_int, [c_int, c_int, c_int, ctypes.POINTER(VolumeParams)]),
+    "msnet_build_volume_ndhwc": (c_int, [P, P, c_int, c_int, c_int, ctypes.POINTER(VolumeParams), P, P, P]),
     "msnet_preprocess_out_shape": (c_int, [c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "msnet_preprocess_image": (c_int, [P, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_double), P, P, P]),
     "msnet_ncdhw_to_ndhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
@@ -64,6 +66,7 @@ SIGNATURES = {
     "msnet_conv3d_k3_wd_f16s_supported": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int]),
     "msnet_conv3d_k3_wd_f16s": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_conv3d_k3_c8_ncdhw_f16s": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "msnet_conv3d_k3_c8_in_f16s": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_conv3d_k3_cout1": (c_int, [P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_softargmin": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "msnet_deconv5_softargmin": (c_int, [P, P, c_float, c_float, P, c_int, c_int, c_int, c_int, c_int, P]),

@@ -73,9 +73,16 @@ def extract_features_lr(census, ncc, sobel, sad, cens_sigma=128.0, ncc_sigma=0.0
 
 
 class VolumeBuilder:
-    """Fused build: owns the workspace for one (Hb, Wb, ndisp) shape so repeated calls allocate nothing."""
+    """Fused build: owns the workspace for one (Hb, Wb, ndisp) shape so repeated calls allocate nothing.
+    layout "ncdhw" (default): out [8, D', H', W'] -- the reference's layout (cbmv_generator.py:307-308), the drop-in.
+    layout "ndhwc": out [D', H', W', 8] -- the aggregator kernels' own layout, for GCNet_CostVolumeAggre.forward_ndhwc: the
+    802 MB layout pass between build and aggregator disappears.  Same values bit for bit.  Shapes / parameters the
+    channels-last kernel does not take (msnet_build_volume_ndhwc_supported) are built NCDHW and converted."""
 
-    def __init__(self, Hb, Wb, ndisp, device="cuda", params=None):
+    def __init__(self, Hb, Wb, ndisp, device="cuda", params=None, layout="ncdhw"):
+        if layout not in ("ncdhw", "ndhwc"):
+            raise ValueError("layout must be 'ncdhw' or 'ndhwc'")
+        self.layout = layout
         lib = _lib.load()
         self.Hb, self.Wb, self.nd = int(Hb), int(Wb), int(ndisp)
         self.params = _lib.VolumeParams()
@@ -86,6 +93,13 @@ class VolumeBuilder:
         self.Wc = self.Wb - 2 * self.params.border_w
         nbytes = lib.msnet_build_volume_workspace_bytes(self.Hb, self.Wb, self.nd)
         self.workspace = torch.empty(max(1, nbytes), device=device, dtype=torch.uint8)
+        self.native_cl = bool(layout == "ndhwc" and lib.msnet_build_volume_ndhwc_supported(self.Hb, self.Wb, self.nd,
+                                                                                             ctypes.byref(self.params)))
+        self._tmp = None
+
+    @property
+    def out_shape(self):
+        return (self.nd, self.Hc, self.Wc, 8) if self.layout == "ndhwc" else (8, self.nd, self.Hc, self.Wc)
 
     def __call__(self, imgl, imgr, out=None):
         imgl = _lib.require_gpu_f32(imgl, "imgl", torch.uint8)
@@ -93,21 +107,36 @@ class VolumeBuilder:
         if tuple(imgl.shape) != (self.Hb, self.Wb) or imgl.shape != imgr.shape:
             raise ValueError("expected two [%d,%d] uint8 images" % (self.Hb, self.Wb))
         if out is None:
-            out = torch.empty((8, self.nd, self.Hc, self.Wc), device=imgl.device, dtype=torch.float32)
+            out = torch.empty(self.out_shape, device=imgl.device, dtype=torch.float32)
+        elif tuple(out.shape) != self.out_shape or not out.is_contiguous() or out.dtype != torch.float32:
+            raise ValueError("out must be a contiguous float32 %s tensor" % (self.out_shape,))
+        if self.native_cl:
+            check(_lib.load().msnet_build_volume_ndhwc(ptr(imgl), ptr(imgr), self.Hb, self.Wb, self.nd, ctypes.byref(self.params),
+                                                       ptr(self.workspace), ptr(out), stream_ptr()), "msnet_build_volume_ndhwc")
+            return out
+        dst = out
+        if self.layout == "ndhwc":          # not taken channels-last by the kernel: NCDHW build + one conversion
+            if self._tmp is None:
+                self._tmp = torch.empty((8, self.nd, self.Hc, self.Wc), device=imgl.device, dtype=torch.float32)
+            dst = self._tmp
         check(_lib.load().msnet_build_volume(ptr(imgl), ptr(imgr), self.Hb, self.Wb, self.nd, ctypes.byref(self.params),
-                                             ptr(self.workspace), ptr(out), stream_ptr()), "msnet_build_volume")
+                                             ptr(self.workspace), ptr(dst), stream_ptr()), "msnet_build_volume")
+        if dst is not out:
+            check(_lib.load().msnet_ncdhw_to_ndhwc(ptr(dst), ptr(out), 1, 8, self.nd, self.Hc, self.Wc, stream_ptr()),
+                  "msnet_ncdhw_to_ndhwc")
         return out
 
 
-def build_ms_volume(imgl_board, imgr_board, ndisp, params=None):
-    """Two bordered uint8 images [Hb, Wb] (NumPy or GPU tensors) -> [8, ndisp, Hb-2*border, Wb-2*border]."""
+def build_ms_volume(imgl_board, imgr_board, ndisp, params=None, layout="ncdhw"):
+    """Two bordered uint8 images [Hb, Wb] (NumPy or GPU tensors) -> [8, ndisp, Hb-2*border, Wb-2*border]
+    (layout="ndhwc": [ndisp, H', W', 8], see VolumeBuilder)."""
     was_numpy = isinstance(imgl_board, np.ndarray)
     if was_numpy:
         if not torch.cuda.is_available():
             raise RuntimeError("build_ms_volume (HIP): no MI355X device visible and there is no CPU fallback")
         imgl_board = torch.from_numpy(np.ascontiguousarray(imgl_board)).cuda()
         imgr_board = torch.from_numpy(np.ascontiguousarray(imgr_board)).cuda()
-    vb = VolumeBuilder(imgl_board.shape[0], imgl_board.shape[1], ndisp, imgl_board.device, params)
+    vb = VolumeBuilder(imgl_board.shape[0], imgl_board.shape[1], ndisp, imgl_board.device, params, layout=layout)
     out = vb(imgl_board, imgr_board)
     return out.cpu().numpy() if was_numpy else out
 

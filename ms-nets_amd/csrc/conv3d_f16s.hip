@@ -1665,7 +1665,8 @@ __global__ void pack_weight_c8_f16s_kernel(const float* __restrict__ w, _Float16
 // instruction), so the separate NCDHW -> NDHWC pass over the 401 MB volume (0.14 ms, 802 MB of traffic) does not exist on
 // this path.  The fp16-range check of the module input, which that pass carried, is made here on the staged values (bit 1 of
 // the overflow word).  Slots: thread t holds voxels t, t+256, ... of the tile, both channel quads (NL = 2 * ceil(NPOS/256)).
-template <int NB, bool NCS>
+// INCHK: the input IS the module input (NCS, or a channels-last volume handed to forward_ndhwc): check its fp16 range here.
+template <int NB, bool NCS, bool INCHK = NCS>
 __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(ConvArgs a) {    // (Co = 64: 128 accumulator registers, one workgroup per CU)
     constexpr int TD = 2, TH = 4, TW = 32, ID = TD + 2, IH = TH + 2, IW = TW + 2, NPOS = ID * IH * IW;
     constexpr int NSLOT = NCS ? ((NPOS + 255) / 256) * 512 : NPOS * 2;
@@ -1747,7 +1748,7 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(Co
             const int pos = slot_pos(u), q = slot_q(u);
             if (pos < NPOS) {
                 half4 hi, lo;
-                if constexpr (NCS) in_amax = max(max(in_amax, max(magnitude_bits(av[u][0]), magnitude_bits(av[u][1]))), max(magnitude_bits(av[u][2]), magnitude_bits(av[u][3])));
+                if constexpr (INCHK) in_amax = max(max(in_amax, max(magnitude_bits(av[u][0]), magnitude_bits(av[u][1]))), max(magnitude_bits(av[u][2]), magnitude_bits(av[u][3])));
                 split4(av[u], hi, lo);
                 const int sw = ((pos >> 3) & 1) * 16;
                 *reinterpret_cast<half4*>(lds_a + pos * 32 + sw + q * 8) = hi;
@@ -1845,13 +1846,13 @@ __global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(Co
             }
         }
     }
-    if constexpr (NCS) {
+    if constexpr (INCHK) {
         // magnitude bits: out-of-range values, inf and NaN all compare >= the limit's bits
         if (a.oflag && in_amax >= kSplitMaxBits) atomicOr(a.oflag, 2u);
     }
 }
 
-template <int NB, bool NCS = false>
+template <int NB, bool NCS = false, bool INCHK = NCS>
 static int launch_c8_f16s(const char* name, ConvArgs a, hipStream_t s) {
     a.ntd = cdiv(a.OD, 2); a.nth = cdiv(a.OH, 4); a.ntw = cdiv(a.OW, 32);
     const size_t ntiles = (size_t)a.N * a.ntd * a.nth * a.ntw;
@@ -1863,7 +1864,7 @@ static int launch_c8_f16s(const char* name, ConvArgs a, hipStream_t s) {
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
                    4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((conv3d_c8_f16s_kernel<NB, NCS>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv3d_c8_f16s_kernel<NB, NCS, INCHK>), dim3((unsigned)nblk), dim3(256), 0, s, a);
     return check_launch(name);
 }
 
@@ -2627,6 +2628,22 @@ extern "C" int msnet_conv3d_k3_c8_ncdhw_f16s(const float* x_ncdhw, const void* w
     hipStream_t s = (hipStream_t)stream;
     if (Co == 64) return launch_c8_f16s<2, true>("conv3d_s1_c8_f16s", a, s);
     return launch_c8_f16s<1, true>("conv3d_s1_c8_f16s", a, s);
+}
+
+// First layer on a channels-last MODULE INPUT x: f32[N][D][H][W][8] (msnet_build_volume_ndhwc's layout): the NDHWC first-layer
+// kernel plus the fp16-range check of the module input that the layout-conversion pass carries on the NCDHW route.
+extern "C" int msnet_conv3d_k3_c8_in_f16s(const float* x_ndhwc, const void* wpk_f16s, const float* scale, const float* shift,
+                                          float* y, int N, int D, int H, int W, int Co, int relu, msnet_stream_t stream) {
+    if (!x_ndhwc || !wpk_f16s || !y) return fail("msnet_conv3d_k3_c8_in_f16s: null pointer");
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_conv3d_k3_c8_in_f16s: empty input");
+    if (Co != 32 && Co != 64) return fail("msnet_conv3d_k3_c8_in_f16s: Co=%d (32 or 64)", Co);
+    ConvArgs a{};
+    a.x = x_ndhwc; a.wpk = reinterpret_cast<const f32x4*>(wpk_f16s); a.scale = scale; a.shift = shift; a.res = nullptr; a.y = y;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = 8; a.Co = Co; a.relu = relu; a.oflag = overflow_flag();
+    a.OD = D; a.OH = H; a.OW = W;
+    hipStream_t s = (hipStream_t)stream;
+    if (Co == 64) return launch_c8_f16s<2, false, true>("conv3d_s1_c8_f16s", a, s);
+    return launch_c8_f16s<1, false, true>("conv3d_s1_c8_f16s", a, s);
 }
 
 // Winograd-depth form of a 32 -> 32 stride-1 layer: g36 = f32 [32][32][36] transformed (BN-folded, pre-scaled) weights, tap

@@ -804,7 +804,7 @@ static int sadsob_impl(const float* sl, const float* sr, float* out, float* ws, 
 bool volume_fast_supported(const msnet_volume_params& p, int Hb, int Wb, int nd);
 size_t volume_fast_workspace_bytes(int Hb, int Wb, int nd);
 int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int nd, const msnet_volume_params& p, void* workspace,
-                       float* out, hipStream_t s);
+                       float* out, hipStream_t s, bool channels_last);
 
 }  // namespace msnet
 
@@ -949,7 +949,7 @@ extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, in
     // MSNET_VOLUME_GENERIC=1 forces the run-time-window kernels below (A/B tests of the two paths)
     const char* generic = getenv("MSNET_VOLUME_GENERIC");
     if (!(generic && generic[0] == '1') && volume_fast_supported(p, Hb, Wb, ndisp))
-        return volume_fast_launch(l, r, Hb, Wb, ndisp, p, workspace, out, s);
+        return volume_fast_launch(l, r, Hb, Wb, ndisp, p, workspace, out, s, false);
     const size_t img = (size_t)Hb * Wb;
     LaunchScope whole("vol_build", s, 0, 4.0 * 8.0 * ndisp * (double)Hc * Wc + 2.0 * img);     // the whole build (bench.py's roofline_volume)
     float* integ = (float*)workspace;
@@ -990,6 +990,27 @@ extern "C" int msnet_build_volume(const uint8_t* l, const uint8_t* r, int Hb, in
             hipLaunchKernelGGL((features_all_kernel<0, 0, 0, 0>), gf, dim3(256), 0, s, a);
     }
     return check_launch("msnet_build_volume");
+}
+
+extern "C" int msnet_build_volume_ndhwc_supported(int Hb, int Wb, int ndisp, const msnet_volume_params* pp) {
+    msnet_volume_params p;
+    if (pp) p = *pp; else msnet_volume_default_params(&p);
+    if (Hb <= 0 || Wb <= 0 || ndisp <= 0) return 0;
+    const int Hc = Hb - 2 * p.border_h, Wc = Wb - 2 * p.border_w;
+    if (p.border_h < 0 || p.border_w < 0 || Hc <= 0 || Wc <= 0) return 0;
+    return volume_fast_supported(p, Hb, Wb, ndisp) && (size_t)ndisp * Hc * Wc * 32 <= 0xfffffff0u ? 1 : 0;
+}
+
+extern "C" int msnet_build_volume_ndhwc(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int ndisp,
+                                        const msnet_volume_params* pp, void* workspace, float* out, msnet_stream_t stream) {
+    msnet_volume_params p;
+    if (pp) p = *pp; else msnet_volume_default_params(&p);
+    if (!l || !r || !workspace || !out) return fail("msnet_build_volume_ndhwc: null pointer");
+    if (!msnet_build_volume_ndhwc_supported(Hb, Wb, ndisp, &p))
+        return fail("msnet_build_volume_ndhwc: only the reference's own windows (11/3/5/5), borders >= 6 and D' a multiple of 8 up "
+                    "to 96 are built channels-last; use msnet_build_volume + msnet_ncdhw_to_ndhwc");
+    if (int e = check_img("msnet_build_volume_ndhwc", l, r, out, Hb, Wb, ndisp, p.censw)) return e;
+    return volume_fast_launch(l, r, Hb, Wb, ndisp, p, workspace, out, (hipStream_t)stream, true);
 }
 
 extern "C" int msnet_preprocess_out_shape(int h, int w, int encoder_ds, int ds, int border, int* Hb, int* Wb) {

@@ -28,6 +28,7 @@
 
 namespace msnet {
 
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
 constexpr int kCW = 11, kNW = 3, kSW = 5, kZW = 5;      // census / NCC / Sobel-SAD / ZSAD windows of the fast path
 constexpr int kMaxBands = 28;                           // Sobel-SAD row bands per image (host-checked)
 constexpr int kBandRMin = 11;                           // smallest band height any configuration uses (workspace sizing)
@@ -305,72 +306,68 @@ __device__ __forceinline__ float aml_e(float c, float m, float sigma, float rsig
     return expf(-q);
 }
 
-// M: 0 census, 1 NCC, 2 Sobel-SAD (raw costs parked in its likelihood channel by sadsob_band_kernel), 3 ZSAD.
+// M: 0 census, 1 NCC, 2 Sobel-SAD (raw costs parked by sadsob_band_kernel), 3 ZSAD.
 // ND: compile-time bound on the disparities (register array); nd <= ND, nd % 8 == 0.
-template <int M, int ND>
-__device__ __forceinline__ void features_px(const FastArgs& a, unsigned char* smem) {
-    constexpr int SW_ = 64 + ND - 1;                       // strip columns: right-image column x - d, d = 0..ND-1
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int xc0 = blockIdx.x * 64, yc0 = blockIdx.y * 4;
-    const int xb0 = xc0 + a.bw, yb0 = yc0 + a.bh;
-    const int W = a.Wb, H = a.Hb, nd = a.nd;
-    const int tid = threadIdx.x;
+// TR: rows of the pixel tile whose right-image strips are staged together (4: features4_kernel, 1: features_cl_kernel).
 
-    // ---- stage the right-image data of this tile's rows in LDS: strip column s <-> image column xb0 - (ND-1) + s
+// LDS bytes of matcher M's right-image strips for a TR-row tile
+template <int M, int ND, int TR> constexpr size_t strip_bytes() {
+    constexpr size_t SW_ = 64 + ND - 1;
+    return M == 0 ? TR * SW_ * 16 : M == 1 ? TR * SW_ * 16 + (TR + 2) * (SW_ + 2) : M == 3 ? TR * SW_ * 4 + (TR + 4) * (SW_ + 4) * 4 : 0;
+}
+
+// Stage the right-image data of the tile rows yb0 .. yb0+TR-1 in LDS: strip column s <-> image column xb0 - (ND-1) + s.
+// Called by NT threads with t = 0..NT-1 (the caller synchronises them afterwards).
+template <int M, int ND, int TR>
+__device__ __forceinline__ void stage_right(const FastArgs& a, unsigned char* smem, int xb0, int yb0, int t, int NT) {
+    constexpr int SW_ = 64 + ND - 1;
+    const int W = a.Wb, H = a.Hb;
     if (M == 0) {
-        uint4* sb = reinterpret_cast<uint4*>(smem);        // [4][SW_]
-        for (int k = tid; k < 4 * SW_; k += 256) {
+        uint4* sb = reinterpret_cast<uint4*>(smem);        // [TR][SW_]
+        for (int k = t; k < TR * SW_; k += NT) {
             const int r = k / SW_, s = k % SW_;
             const int gy = yb0 + r, gx = xb0 - (ND - 1) + s;
             sb[k] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? a.rb[(size_t)gy * W + gx] : make_uint4(0, 0, 0, 0);
         }
     } else if (M == 1) {
-        double2* st = reinterpret_cast<double2*>(smem);    // [4][SW_] tables
-        uint8_t* si = smem + 4 * SW_ * 16;                  // [6][SW_ + 2] pixels, image column xb0 - 1 - (ND-1) + s
-        for (int k = tid; k < 4 * SW_; k += 256) {
+        double2* st = reinterpret_cast<double2*>(smem);    // [TR][SW_] tables
+        uint8_t* si = smem + TR * SW_ * 16;                 // [TR + 2][SW_ + 2] pixels, image column xb0 - 1 - (ND-1) + s
+        for (int k = t; k < TR * SW_; k += NT) {
             const int r = k / SW_, s = k % SW_;
             const int gy = yb0 + r, gx = xb0 - (ND - 1) + s;
             st[k] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? a.ncr[(size_t)gy * W + gx] : make_double2(0.0, 0.0);
         }
-        for (int k = tid; k < 6 * (SW_ + 2); k += 256) {
+        for (int k = t; k < (TR + 2) * (SW_ + 2); k += NT) {
             const int r = k / (SW_ + 2), s = k % (SW_ + 2);
             const int gy = yb0 - 1 + r, gx = xb0 - 1 - (ND - 1) + s;
             si[k] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? a.r[gy * W + gx] : 0;
         }
     } else if (M == 3) {
-        float* sm = reinterpret_cast<float*>(smem);        // [4][SW_] means
-        float* si = sm + 4 * SW_;                           // [8][SW_ + 4] pixels as float, image column xb0 - 2 - (ND-1) + s
-        for (int k = tid; k < 4 * SW_; k += 256) {
+        float* sm = reinterpret_cast<float*>(smem);        // [TR][SW_] means
+        float* si = sm + TR * SW_;                          // [TR + 4][SW_ + 4] pixels as float, image column xb0 - 2 - (ND-1) + s
+        for (int k = t; k < TR * SW_; k += NT) {
             const int r = k / SW_, s = k % SW_;
             const int gy = yb0 + r, gx = xb0 - (ND - 1) + s;
             sm[k] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? a.mr[(size_t)gy * W + gx] : 0.f;
         }
-        for (int k = tid; k < 8 * (SW_ + 4); k += 256) {
+        for (int k = t; k < (TR + 4) * (SW_ + 4); k += NT) {
             const int r = k / (SW_ + 4), s = k % (SW_ + 4);
             const int gy = yb0 - 2 + r, gx = xb0 - 2 - (ND - 1) + s;
             si[k] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? (float)a.r[gy * W + gx] : 0.f;
         }
     }
-    if (M != 2) __syncthreads();
+}
 
-    const int x = xc0 + tx, y = yc0 + ty;
-    if (x >= a.Wc || y >= a.Hc) return;
-    const int xb = x + a.bw, yb = y + a.bh;
-    const size_t plane = (size_t)a.Hc * a.Wc;
-    // One buffer descriptor per output channel: a store is {descriptor, per-lane byte offset of the pixel, SCALAR byte
-    // offset of the disparity plane} -- no per-store 64-bit address arithmetic on the vector unit.
-    const unsigned pix4 = (unsigned)(y * a.Wc + x) * 4u;
-    const unsigned plane4 = (unsigned)plane * 4u;
-    const unsigned chan_bytes = (unsigned)nd * plane4;     // <= 4 GB checked on the host
-    const __amdgpu_buffer_rsrc_t o_cost = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)M * nd * plane, 0, (int)chan_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t o_aml = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)(4 + M) * nd * plane, 0, (int)chan_bytes, 0x00020000);
+// Pass 1: the nd raw costs of bordered pixel (yb, xb) = tile row ty, tile column tx, into registers.  The border (>= 6) makes
+// every window of a cropped pixel spatially valid, so only the disparity range is tested: census d <= xb - 5
+// (matchers.cpp:318), the others d <= window-left column.  M == 2 reads the parked Sobel-SAD costs [nd][Hc][Wc] through
+// `park` (descriptor) at byte offset pix4 + d * plane4.
+template <int M, int ND, int TR>
+__device__ __forceinline__ void raw_costs(const FastArgs& a, const unsigned char* smem, int tx, int ty, int xb, int yb, int nd,
+                                          __amdgpu_buffer_rsrc_t park, unsigned pix4, unsigned plane4, float (&c)[ND]) {
+    constexpr int SW_ = 64 + ND - 1;
+    const int W = a.Wb;
     const size_t pl = (size_t)yb * W + xb;
-
-    float c[ND];
-    float m = kSentinel;
-
-    // ---- pass 1: raw costs.  The border (>= 6) makes every window of a cropped pixel spatially valid, so only the
-    // disparity range is tested: census d <= xb - 5 (matchers.cpp:318), the others d <= window-left column.
     if (M == 0) {
         const uint4 lw = a.lb[pl];
         const uint4* sb = reinterpret_cast<const uint4*>(smem) + ty * SW_ + tx + (ND - 1);
@@ -392,7 +389,7 @@ __device__ __forceinline__ void features_px(const FastArgs& a, unsigned char* sm
         const double Al = tl.x, Cl = tl.y;
         const bool lfin = isfinite(Cl);
         const double2* st = reinterpret_cast<const double2*>(smem) + ty * SW_ + tx + (ND - 1);
-        const uint8_t* si = smem + 4 * SW_ * 16 + ty * (SW_ + 2) + tx + (ND - 1);     // window top-left of d = 0
+        const uint8_t* si = smem + TR * SW_ * 16 + ty * (SW_ + 2) + tx + (ND - 1);     // window top-left of d = 0
         unsigned lv[9];
 #pragma unroll
         for (int k = 0; k < 9; ++k) lv[k] = a.l[(yb - 1 + k / 3) * W + xb - 1 + k % 3];
@@ -435,13 +432,13 @@ __device__ __forceinline__ void features_px(const FastArgs& a, unsigned char* sm
             if (d0 < nd) {
 #pragma unroll
                 for (int u = 0; u < 8; ++u)
-                    c[d0 + u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(o_aml, pix4, (unsigned)(d0 + u) * plane4, 0));
+                    c[d0 + u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(park, pix4, (unsigned)(d0 + u) * plane4, 0));
             }
         }
     } else {
         const float mlv = a.ml[pl];
         const float* sm = reinterpret_cast<const float*>(smem) + ty * SW_ + tx + (ND - 1);
-        const float* si = reinterpret_cast<const float*>(smem) + 4 * SW_ + ty * (SW_ + 4) + tx + (ND - 1);   // window top-left, d = 0
+        const float* si = reinterpret_cast<const float*>(smem) + TR * SW_ + ty * (SW_ + 4) + tx + (ND - 1);   // window top-left, d = 0
         float lm[25];
 #pragma unroll
         for (int k = 0; k < 25; ++k) lm[k] = (float)a.l[(yb - 2 + k / 5) * W + xb - 2 + k % 5] - mlv;
@@ -476,6 +473,34 @@ __device__ __forceinline__ void features_px(const FastArgs& a, unsigned char* sm
             }
         }
     }
+}
+
+template <int M, int ND>
+__device__ __forceinline__ void features_px(const FastArgs& a, unsigned char* smem) {
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int xc0 = blockIdx.x * 64, yc0 = blockIdx.y * 4;
+    const int xb0 = xc0 + a.bw, yb0 = yc0 + a.bh;
+    const int nd = a.nd;
+
+    stage_right<M, ND, 4>(a, smem, xb0, yb0, threadIdx.x, 256);
+    if (M != 2) __syncthreads();
+
+    const int x = xc0 + tx, y = yc0 + ty;
+    if (x >= a.Wc || y >= a.Hc) return;
+    const int xb = x + a.bw, yb = y + a.bh;
+    const size_t plane = (size_t)a.Hc * a.Wc;
+    // One buffer descriptor per output channel: a store is {descriptor, per-lane byte offset of the pixel, SCALAR byte
+    // offset of the disparity plane} -- no per-store 64-bit address arithmetic on the vector unit.
+    const unsigned pix4 = (unsigned)(y * a.Wc + x) * 4u;
+    const unsigned plane4 = (unsigned)plane * 4u;
+    const unsigned chan_bytes = (unsigned)nd * plane4;     // <= 4 GB checked on the host
+    const __amdgpu_buffer_rsrc_t o_cost = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)M * nd * plane, 0, (int)chan_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t o_aml = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)(4 + M) * nd * plane, 0, (int)chan_bytes, 0x00020000);
+
+    float c[ND];
+    float m = kSentinel;
+    // ---- pass 1: raw costs (the Sobel-SAD costs were parked in this matcher's likelihood channel by sadsob_band_kernel)
+    raw_costs<M, ND, 4>(a, smem, tx, ty, xb, yb, nd, o_aml, pix4, plane4, c);
 
     // normalised cost channel + min
 #pragma unroll
@@ -538,6 +563,115 @@ __global__ __launch_bounds__(256, 3) void features4_kernel(FastArgs a, int zbase
     default: features_px<2, ND>(a, smem); break;
     }
 }
+// ------------------------------------------------------------------------------------------------ channels-last features
+// features_cl_kernel writes the volume as [D'][H'][W'][8] -- one 32-byte voxel record per (d, y, x), the first conv layer's
+// own input layout -- so the 802 MB NCDHW -> NDHWC pass between the volume build and the aggregator does not exist on this
+// path.  A workgroup owns a 64-pixel row segment and ALL FOUR matchers: wave w computes matcher (w + block) & 3 for the 64
+// pixels with the D' raw costs in registers exactly as features_px does (same code: stage_right / raw_costs), then the four
+// waves meet per group of eight disparities in an LDS tile [8 d][8 ch][64 px] and the 256 threads write it out as whole
+// voxels: every store instruction of a wave covers 1 KB of contiguous output.  Both channels of a matcher must exist at the
+// same time for that, so the likelihood numerator expf(-(c_d - m)^2 / sigma) is evaluated twice (once for the denominator,
+// once for the value) instead of being kept in the cost's register -- same bits, one more expf per element.
+constexpr int kClPitch = 72;       // floats per LDS tile row: 64 pixels + 8, so that the two half-voxel readers of a pixel (rows
+                                   // 4 apart: 4 * 72 = 288 = 32 mod 64) fall on disjoint bank halves
+template <int ND> constexpr size_t features_cl_strip_bytes() {
+    constexpr size_t m0 = strip_bytes<0, ND, 1>(), m1 = strip_bytes<1, ND, 1>(), m3 = strip_bytes<3, ND, 1>();
+    return ((m0 > m1 ? (m0 > m3 ? m0 : m3) : (m1 > m3 ? m1 : m3)) + 15) & ~(size_t)15;
+}
+
+template <int M, int ND>
+__device__ __forceinline__ void features_cl_wave(const FastArgs& a, unsigned char* strip, float* tbuf, const float* park_base) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int xc0 = blockIdx.x * 64, y = blockIdx.y;
+    const int nd = a.nd;
+    stage_right<M, ND, 1>(a, strip, xc0 + a.bw, y + a.bh, lane, 64);
+    __syncthreads();
+    const int x = min(xc0 + lane, a.Wc - 1);               // lanes past the row end recompute its last pixel (never stored)
+    const size_t plane = (size_t)a.Hc * a.Wc;
+    const unsigned pix4 = (unsigned)(y * a.Wc + x) * 4u;
+    const unsigned plane4 = (unsigned)plane * 4u;
+    const __amdgpu_buffer_rsrc_t park = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(park_base), 0, (int)((unsigned)nd * plane4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t o_all = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)nd * plane4 * 8u), 0x00020000);
+
+    float c[ND];
+    raw_costs<M, ND, 1>(a, strip, x - xc0, 0, x + a.bw, y + a.bh, nd, park, pix4, plane4, c);
+    float m = kSentinel;
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+        if (d < nd && c[d] < m) m = c[d];
+    // ---- pass 2: the denominator, accumulated in d order (featextract.cpp:444-447)
+    const float sigma = a.sigma[M], rsigma = a.rsigma[M];
+    float den = 0.f;
+#pragma unroll
+    for (int d0 = 0; d0 < ND; d0 += 8) {
+        if (d0 < nd) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                den += aml_e(c[d0 + u], m, sigma, rsigma);
+                if (u & 1) __builtin_amdgcn_sched_barrier(0);      // two expf in flight, not eight: all ND costs stay live here
+            }
+        }
+    }
+    const bool dead = (m == kSentinel);                    // all-sentinel row -> zeros (featextract.cpp:452)
+    const float rden = 1.f / den;                          // den >= 1: the minimum contributes expf(0)
+    // ---- pass 3: eight disparities at a time through the LDS tile, written out as whole voxels
+    // store role: float4 number f = tid + 256 k of the tile's 1024 (8 d x 64 px x 2 halves): d = f >> 7, px = (f & 127) >> 1
+    unsigned voff[4];
+    int srow[4];
+    int tq = tid;
+    float m3 = m;
+    // Opaque copies: (i) the store role's coordinates are computed BEHIND pass 2 -- during the raw-cost pass (ZSAD: 155
+    // registers) they would be spilled; (ii) pass 3 recomputes (c_d - m)^2 / sigma from its own copy of m -- otherwise the
+    // compiler keeps pass 2's ND quotients alive next to the ND costs (192 registers + spills) instead of re-deriving them.
+    asm volatile("" : "+v"(tq), "+v"(den), "+v"(m3));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int f = tq + 256 * k, u = f >> 7, px = (f & 127) >> 1, half = f & 1;
+        srow[k] = (u * 8 + half * 4) * kClPitch + px;
+        voff[k] = xc0 + px < a.Wc ? (unsigned)(((size_t)u * plane + (size_t)y * a.Wc + xc0 + px) * 32u + half * 16u) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int d0 = 0; d0 < ND; d0 += 8) {
+        if (d0 < nd) {
+            float* buf = tbuf + ((d0 >> 3) & 1) * (64 * kClPitch);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + u;
+                const float e = aml_e(c[d], m3, sigma, rsigma);
+                buf[(u * 8 + M) * kClPitch + lane] = norm_cost(M, c[d]);
+                buf[(u * 8 + 4 + M) * kClPitch + lane] = dead ? 0.f : div_rn(e, den, rden);
+                if (u & 1) __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();                               // (the other tile buffer is free again: its readers passed this barrier)
+            const unsigned dbase = (unsigned)d0 * plane4 * 8u;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                f32x4 v;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = buf[srow[k] + j * kClPitch];
+                const unsigned off = voff[k] == 0xffffffffu ? 0xffffffffu : voff[k] + dbase;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), o_all, off, 0, 0);
+            }
+        }
+    }
+}
+
+template <int ND>
+__global__ __launch_bounds__(256, 3) void features_cl_kernel(FastArgs a, const float* park) {
+    constexpr size_t SB = features_cl_strip_bytes<ND>();
+    __shared__ __attribute__((aligned(16))) unsigned char strips[4 * SB];
+    __shared__ __attribute__((aligned(16))) float tbuf[2 * 64 * kClPitch];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    unsigned char* strip = strips + wave * SB;
+    // the long-running ZSAD wave rotates over the four SIMDs from block to block
+    switch ((wave + blockIdx.x + blockIdx.y) & 3) {
+    case 0: features_cl_wave<3, ND>(a, strip, tbuf, park); break;
+    case 1: features_cl_wave<1, ND>(a, strip, tbuf, park); break;
+    case 2: features_cl_wave<0, ND>(a, strip, tbuf, park); break;
+    default: features_cl_wave<2, ND>(a, strip, tbuf, park); break;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ host
 static int band_ls(int Wb) {
     int LS = Wb + 1;
@@ -564,7 +698,9 @@ bool volume_fast_supported(const msnet_volume_params& p, int Hb, int Wb, int nd)
 size_t volume_fast_workspace_bytes(int Hb, int Wb, int nd) {
     const size_t img = (size_t)Hb * Wb;
     const int Hc = Hb > 12 ? Hb - 12 : 1;                  // at least border 6; more border = fewer bands
-    return img * (2 * 16 + 2 * 16 + 4 * 4) + (size_t)nd * cdiv(Hc, kBandRMin) * band_ls(Wb) * sizeof(float) + 256;
+    // + the parked Sobel-SAD raw costs [nd][Hc][Wc] of the channels-last build (the NCDHW build parks them in its output)
+    return img * (2 * 16 + 2 * 16 + 4 * 4) + (size_t)nd * cdiv(Hc, kBandRMin) * band_ls(Wb) * sizeof(float) + 256 +
+           (size_t)nd * Hc * (Wb > 12 ? Wb - 12 : 1) * sizeof(float) + 256;
 }
 
 // Second stream of the build: the Sobel-SAD kernels (one wave per workgroup busy most of the time, LDS-capacity-bound) run
@@ -572,21 +708,38 @@ size_t volume_fast_workspace_bytes(int Hb, int Wb, int nd) {
 // stream and two events per (device, caller stream), created on first use: builds issued on DIFFERENT streams (two host
 // threads, two VolumeBuilders) never share an event; builds on one stream are ordered by that stream.  fork / join are
 // ordinary event waits, so the build stays asynchronous on the caller's stream and capturable.
-struct VolAux { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; };
+struct VolAux { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; unsigned long long used = 0; };
+constexpr size_t kMaxVolAux = 16;      // helper streams kept alive at once (callers that build on many short-lived streams)
 static VolAux& vol_aux(hipStream_t caller) {
     static std::map<std::pair<int, hipStream_t>, VolAux*> aux;
     static std::mutex mu;
+    static unsigned long long tick = 0;
     std::lock_guard<std::mutex> lk(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-    VolAux*& x = aux[std::make_pair(dev, caller)];
-    if (!x) {
-        x = new VolAux();
+    const auto key = std::make_pair(dev, caller);
+    auto it = aux.find(key);
+    if (it == aux.end()) {
+        if (aux.size() >= kMaxVolAux) {
+            // least recently used entry goes: its helper stream is destroyed (HIP lets queued work finish first) together with
+            // its events.  A caller stream whose entry was evicted simply gets a new one on its next build.
+            auto old = aux.begin();
+            for (auto j = aux.begin(); j != aux.end(); ++j) if (j->second->used < old->second->used) old = j;
+            VolAux* v = old->second;
+            if (v->fork) (void)hipEventDestroy(v->fork);
+            if (v->join) (void)hipEventDestroy(v->join);
+            if (v->s) (void)hipStreamDestroy(v->s);
+            delete v;
+            aux.erase(old);
+        }
+        VolAux* x = new VolAux();
         x->ok = hipStreamCreateWithFlags(&x->s, hipStreamNonBlocking) == hipSuccess &&
                 hipEventCreateWithFlags(&x->fork, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&x->join, hipEventDisableTiming) == hipSuccess;
+        it = aux.emplace(key, x).first;
     }
-    return *x;
+    it->second->used = ++tick;
+    return *it->second;
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: set once per (device, kernel), under a lock
@@ -603,8 +756,9 @@ static void allow_big_lds(K kernel) {
     }
 }
 
+// channels_last: out is [nd][Hc][Wc][8] (features_cl_kernel) instead of [8][nd][Hc][Wc]
 int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int nd, const msnet_volume_params& p, void* workspace,
-                       float* out, hipStream_t s) {
+                       float* out, hipStream_t s, bool channels_last) {
     const size_t img = (size_t)Hb * Wb;
     FastArgs a{};
     a.l = l; a.r = r;
@@ -613,6 +767,8 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
     a.ncl = (double2*)(a.rb + img); a.ncr = a.ncl + img;
     a.ml = (float*)(a.ncr + img); a.mr = a.ml + img; a.sobl = a.mr + img; a.sobr = a.sobl + img;
     float* ck = a.sobr + img;
+    const int Hc_ws = Hb > 12 ? Hb - 12 : 1;               // the carve below uses the workspace function's own bounds
+    float* park_ws = (float*)(((uintptr_t)(ck + (size_t)nd * cdiv(Hc_ws, kBandRMin) * band_ls(Wb)) + 255) & ~(uintptr_t)255);
     a.out = out;
     a.sigma[0] = p.cens_sigma; a.sigma[1] = p.ncc_sigma; a.sigma[2] = p.sad_sigma; a.sigma[3] = p.sad_sigma;
     for (int k = 0; k < 4; ++k) a.rsigma[k] = 1.f / a.sigma[k];
@@ -628,8 +784,12 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
     constexpr int band_skip = 0, band_cfg = 0;
     constexpr bool want_overlap = true;
 #endif
-    VolAux& aux = vol_aux(s);
-    const bool overlap = want_overlap && aux.ok;
+    if (channels_last && (size_t)nd * plane * 32 > 0xfffffff0u)
+        return fail("msnet_build_volume_ndhwc: the volume exceeds the 4 GB buffer-descriptor range");
+    // (the channels-last feature launch needs all four matchers at once: nothing to overlap the Sobel-SAD kernels with, no helper stream)
+    static VolAux none;
+    VolAux& aux = (channels_last || !want_overlap) ? none : vol_aux(s);
+    const bool overlap = want_overlap && aux.ok && !channels_last;
     hipStream_t sb = overlap ? aux.s : s;                  // stream of the Sobel-SAD kernels
 
     LaunchScope whole("vol_build", s, 0, 4.0 * 8.0 * nd * (double)plane + 2.0 * img);     // the whole build on the caller's stream
@@ -643,7 +803,7 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
     }
     {
         const int LS = band_ls(Wb);
-        float* park = out + (size_t)6 * nd * plane;         // channel 6 = likelihood of the Sobel-SAD cost
+        float* park = channels_last ? park_ws : out + (size_t)6 * nd * plane;     // NCDHW: channel 6 = likelihood of the Sobel-SAD cost
         LaunchScope ls("volk_sadsob", sb, 0, 4.0 * nd * (double)plane);
         auto launch = [&](auto rc, auto ntc) -> int {
             constexpr int R = decltype(rc)::value, NT = decltype(ntc)::value;
@@ -671,7 +831,12 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
         if (nd <= 32) hipLaunchKernelGGL(features4_kernel<32>, g, dim3(256), 0, s, a, zbase);
         else hipLaunchKernelGGL(features4_kernel<96>, g, dim3(256), 0, s, a, zbase);
     };
-    if (overlap) {
+    if (channels_last) {
+        LaunchScope ls("volk_features", s, 0, 4.0 * 8.0 * nd * (double)plane);
+        const dim3 g(gpix.x, a.Hc, 1);
+        if (nd <= 32) hipLaunchKernelGGL(features_cl_kernel<32>, g, dim3(256), 0, s, a, park_ws);
+        else hipLaunchKernelGGL(features_cl_kernel<96>, g, dim3(256), 0, s, a, park_ws);
+    } else if (overlap) {
         {
             LaunchScope ls("volk_features", s, 0, 4.0 * 6.0 * nd * (double)plane);
             features(0, 3);                                 // ZSAD, NCC, census: no dependence on the Sobel-SAD stream

@@ -5,23 +5,101 @@ disparity maps over RCCL/xGMI.  Replaces the reference's single-process nn.DataP
 has no cross-sample state (BN uses running statistics, main_msnet.py:534).
 
 Sharding rule: sample i -> rank i mod world_size.
-On CPU-only hosts the same code runs over gloo (tests/test_dist_gloo.py, world_size 2)."""
+On CPU-only hosts the same code runs over gloo (tests/test_dist_gloo.py, world_size 2).
+
+Backend: RCCL ("nccl") on GPUs by default.  `MSNET_DIST_BACKEND=gloo` (bench.py --dist-backend gloo) keeps the ranks' tensors
+on the GPU and runs the collective through host memory -- RCCL refuses two ranks on one device, gloo does not, so a box with
+ONE GPU can run world_size 2 with both ranks on cuda:0 (LOCAL_RANK modulo the device count) and execute every world > 1
+branch on hardware (tests/test_gpu_bench_contract.py::test_bench_world2_on_one_gpu).  Diagnostic only: never the headline."""
+import glob
 import os
 
 import torch
 import torch.distributed as dist
 
+_ranks_per_device = 1
+
+
+def backend():
+    """'nccl' | 'gloo' | None (no process group)."""
+    return dist.get_backend() if dist.is_available() and dist.is_initialized() else None
+
+
+def ranks_per_device():
+    return _ranks_per_device
+
+
+def _gpu_cards():
+    """amdgpu devices in /sys/class/drm, in card order (the order HIP enumerates them in on a stock node)."""
+    out = []
+    for c in sorted(glob.glob("/sys/class/drm/card[0-9]*/device"), key=lambda p: int(p.split("card")[-1].split("/")[0])):
+        try:
+            if open(os.path.join(c, "vendor")).read().strip() == "0x1002" and os.path.exists(os.path.join(c, "mem_info_vram_total")):
+                out.append(c)
+        except OSError:
+            pass
+    return out
+
+
+def _parse_cpulist(text):
+    cpus = set()
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        lo, _, hi = part.partition("-")
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def bind_to_gpu_numa_node(local_rank):
+    """Pin this process to the CPUs of the NUMA node its GPU hangs off (/sys/class/drm/card*/device/numa_node): on a
+    two-socket 8-GPU node the launch thread of a rank otherwise migrates across sockets, and eight ranks' launch loops and
+    pinned read-backs then cross the socket link.  Reads sysfs only -- call it BEFORE anything touches the GPU.  Returns the
+    node bound to, or None (single-node host, no such file, visible-device remapping that cannot be resolved: nothing done)."""
+    try:
+        cards = _gpu_cards()
+        vis = os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES")
+        if vis:
+            ids = [v.strip() for v in vis.split(",")]
+            if not all(v.isdigit() for v in ids):
+                return None
+            cards = [cards[int(v)] for v in ids if int(v) < len(cards)]
+        if not cards:
+            return None
+        node = int(open(os.path.join(cards[local_rank % len(cards)], "numa_node")).read().strip())
+        if node < 0:
+            return None
+        cpus = _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except (OSError, ValueError, IndexError):
+        return None
+
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun contract).
-    Returns (rank, world_size, local_rank).  A plain single-process run (no RANK) returns (0, 1, 0)."""
+    Returns (rank, world_size, local_rank) -- local_rank already reduced modulo the number of visible GPUs, i.e. the device
+    index to use.  A plain single-process run (no RANK) returns (0, 1, 0)."""
+    global _ranks_per_device
     if "RANK" not in os.environ:
         return 0, 1, 0
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank))
+    backend = backend or os.environ.get("MSNET_DIST_BACKEND") or None
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
     if torch.cuda.is_available():
+        ndev = torch.cuda.device_count()
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
+        if local_world > ndev:
+            if backend == "nccl":
+                raise RuntimeError("%d ranks on %d GPU(s): RCCL needs one device per rank (use one process per GPU, or "
+                                   "MSNET_DIST_BACKEND=gloo for a functional run that shares devices)" % (local_world, ndev))
+            _ranks_per_device = (local_world + ndev - 1) // ndev
+        local = local % ndev
         torch.cuda.set_device(local)
     if not dist.is_initialized():
         os.environ.setdefault("NCCL_DEBUG", "WARN")      # no RCCL version banner on stdout next to a caller's own output
@@ -49,8 +127,15 @@ def gather_disparities(local_disp, n_total):
     if local_disp.shape[0] < n_max:
         send = torch.zeros((n_max, H, W), dtype=local_disp.dtype, device=local_disp.device)
         send[:local_disp.shape[0]] = local_disp
-    recv = torch.empty((world * n_max, H, W), dtype=local_disp.dtype, device=local_disp.device)
-    dist.all_gather_into_tensor(recv, send.contiguous())      # rank-major concatenation along dim 0
+    if dist.get_backend() == "gloo" and send.is_cuda:
+        # functional multi-rank runs on shared devices: the collective goes through host memory, everything around it stays
+        # on the device
+        host = torch.empty((world * n_max, H, W), dtype=local_disp.dtype)
+        dist.all_gather_into_tensor(host, send.contiguous().cpu())
+        recv = host.to(local_disp.device)
+    else:
+        recv = torch.empty((world * n_max, H, W), dtype=local_disp.dtype, device=local_disp.device)
+        dist.all_gather_into_tensor(recv, send.contiguous())      # rank-major concatenation along dim 0
     # recv.view(world, n_max)[r, j] is sample j*world + r
     return recv.view(world, n_max, H, W).permute(1, 0, 2, 3).reshape(world * n_max, H, W)[:n_total].contiguous()
 

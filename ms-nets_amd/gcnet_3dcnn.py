@@ -50,7 +50,7 @@ class Conv3DBlock(nn.Module):
         self.stride = stride
 
 
-class GCNet_CostVolumeAggre(nn.Module):
+class GCNet_CostVolumeAggre(hipops.DeviceStateMixin, nn.Module):
     def __init__(self, maxdisp=192, cbmv_in_planes=8, kernel_size=3, is_quarter_input_size=False):
         super().__init__()
         if kernel_size != 3:
@@ -75,26 +75,18 @@ class GCNet_CostVolumeAggre(nn.Module):
         else:
             self.deconv5 = nn.ConvTranspose3d(F, 1, 3, stride=2, padding=1, output_padding=1)
         net_init(self)
-        self._plan = None
-        self._plan_key = None
+        # per-device state (packed-weight plans, activation arena, range guard, captured graphs): hipops.ModuleState
+        self._init_device_state()
         # fp16-range guard of the split-fp16 kernels (hipops.guarded_forward): costs one 4-byte read-back per forward;
         # set range_check = False when the activations are known to stay below 32752 (hipops.ACT_MAX)
         self.range_check = os.environ.get("MSNET_RANGE_CHECK", "1") != "0"
-        self._forced_precision = None
-        self._guard = None
-        self._arena = hipops.Arena()      # activation buffers reused across forwards (hipops.Arena)
-        self._use_arena = True
         self.use_graph = False            # True: forwards are captured as HIP graphs per input buffer (hipops._graphed_forward)
 
     # ---- device constants ------------------------------------------------------------------------
     def invalidate_plans(self):
         """Drop the packed weights / folded BN constants; the next forward rebuilds them from the current parameters.
         Needed only after edits through `.data` (which leave no trace in the tensors' version counters)."""
-        self._plan = None
-        self._plan_key = None
-        self._forced_precision = None
-        self.__dict__.pop("_graphs", None)        # captured HIP graphs hold the old packed weights
-        self.__dict__.pop("_state_tensors", None)  # hipops.state_key re-walks the module tree
+        self._drop_device_state()          # plans, arenas, range guards, captured graphs (they hold the old packed weights)
 
     def _plans(self, precision):
         key = hipops.state_key(self)
@@ -119,16 +111,34 @@ class GCNet_CostVolumeAggre(nn.Module):
     def forward(self, cv, taps=None):
         """cv [N,C,D',H',W'] -> disparity [N,H,W].  `taps`: optional dict that receives every layer output
         converted back to NCDHW under the reference's names (parity tests only)."""
+        if getattr(self, "_is_replica", False):
+            raise RuntimeError(hipops.REPLICA_ERROR)
         if self.training:
             raise RuntimeError("GCNet_CostVolumeAggre (HIP) is forward/inference only: call .eval() first")
         cv = hipops.require_gpu_f32(cv, "cv")
         if cv.dim() != 5:
             raise ValueError("cv must be [N,C,D,H,W]")
-        self._use_arena = taps is None          # tapped activations are handed to the caller: fresh tensors
+        # (tapped activations are handed to the caller: fresh tensors instead of the arena's)
         return hipops.guarded_forward(self, lambda precision: self._forward(cv, taps, precision),
-                                      graph_key=(cv.data_ptr(), tuple(cv.shape)) if taps is None else None)
+                                      graph_key=(cv.data_ptr(), tuple(cv.shape)) if taps is None else None,
+                                      use_arena_=taps is None)
 
-    def _forward(self, cv, taps, precision):
+    def forward_ndhwc(self, cv_cl):
+        """The forward on a CHANNELS-LAST volume cv_cl [N,D',H',W',C] (cbmv_generator.VolumeBuilder(layout="ndhwc") writes it):
+        the aggregator kernels' own activation layout, so no layout pass runs between the volume build and conv3dbn_1.  Same
+        result, bit for bit, as forward(cv) on the NCDHW volume of the same values.  Not part of the reference's interface
+        (its module takes NCDHW, gcnet_3dcnn.py:97-101): forward() stays the drop-in."""
+        if getattr(self, "_is_replica", False):
+            raise RuntimeError(hipops.REPLICA_ERROR)
+        if self.training:
+            raise RuntimeError("GCNet_CostVolumeAggre (HIP) is forward/inference only: call .eval() first")
+        cv_cl = hipops.require_gpu_f32(cv_cl, "cv_cl")
+        if cv_cl.dim() != 5 or cv_cl.shape[4] != self.conv3dbn_1[0].in_channels:
+            raise ValueError("cv_cl must be [N,D,H,W,%d] (got %s)" % (self.conv3dbn_1[0].in_channels, tuple(cv_cl.shape)))
+        return hipops.guarded_forward(self, lambda precision: self._forward(cv_cl, None, precision, channels_last=True),
+                                      graph_key=(cv_cl.data_ptr(), tuple(cv_cl.shape), "ndhwc"))
+
+    def _forward(self, cv, taps, precision, channels_last=False):
         pl = self._plans(precision)
         if taps is not None:
             taps.clear()
@@ -154,7 +164,13 @@ class GCNet_CostVolumeAggre(nn.Module):
 
         with torch.no_grad():
             p1 = pl["conv3dbn_1"]
-            if p1.f16s and cv.shape[1] == 8 and p1.co in (32, 64) and FUSE_INPUT_LAYOUT:
+            if channels_last:
+                if p1.f16s and cv.shape[4] == 8 and p1.co in (32, 64):
+                    x = hipops.conv3d_c8_in(cv, p1.wpk, p1.scale, p1.shift, p1.co, relu=True)     # range check of the input inside
+                else:
+                    # (16-channel volumes, fp32 precision: no input-checking first-layer kernel -- the check rides on a copy)
+                    x = conv(hipops.ncdhw_to_ndhwc(cv.permute(0, 4, 1, 2, 3).contiguous()), "conv3dbn_1")
+            elif p1.f16s and cv.shape[1] == 8 and p1.co in (32, 64) and FUSE_INPUT_LAYOUT:
                 # the first layer reads the NCDHW volume itself: no layout-conversion pass over the 401 MB
                 x = tap("conv3dbn_1", hipops.conv3d_c8_ncdhw(cv, p1.wpk, p1.scale, p1.shift, p1.co, relu=True))
             else:

@@ -40,32 +40,115 @@ class Arena:
         return sum(t.numel() * 4 for t in self.bufs)
 
 
-_arena = None
+class _ThreadState(threading.local):
+    arena = None            # the Arena the wrappers below allocate from ON THIS THREAD (use_arena)
+
+
+_tls = _ThreadState()
 
 
 class use_arena:
-    """Context: activation outputs of the wrappers below come from `arena` (None = plain torch.empty)."""
+    """Context: activation outputs of the wrappers below come from `arena` (None = plain torch.empty) -- for the calling
+    THREAD only: two modules running forwards on two Python threads (one per replica, as under the reference's
+    nn.DataParallel, main_msnet.py:174) each see their own arena."""
 
     def __init__(self, arena):
         self.arena = arena
 
     def __enter__(self):
-        global _arena
-        self.prev, _arena = _arena, self.arena
+        self.prev, _tls.arena = _tls.arena, self.arena
         if self.arena is not None:
             self.arena.k = 0
         return self.arena
 
     def __exit__(self, *exc):
-        global _arena
-        _arena = self.prev
+        _tls.arena = self.prev
         return False
 
 
 def _new(shape, device):
-    if _arena is not None:
-        return _arena.empty(shape, device)
+    if _tls.arena is not None:
+        return _tls.arena.empty(shape, device)
     return torch.empty(shape, device=device, dtype=torch.float32)
+
+
+class _Slot:
+    """Everything a module keeps between forwards FOR ONE DEVICE: activation arena, packed-weight plans, range guard, the
+    sticky fp32 fallback, captured graphs -- and the lock that makes a forward exclusive."""
+
+    def __init__(self):
+        self.arena = Arena()
+        self.plan = None
+        self.plan_key = None
+        self.guard = None
+        self.forced_precision = None
+        self.forced_key = None
+        self.graphs = {}
+        self.lock = threading.RLock()
+        self.last_event = None              # recorded behind the last forward on last_stream (guarded_forward)
+        self.last_stream = None
+
+
+class ModuleState:
+    """Per-device slots of one aggregator module.  The object is shared BY REFERENCE between a module and any shallow copy of
+    it, so two copies can never hand the same activation buffers to two concurrent forwards."""
+
+    def __init__(self):
+        self._slots = {}
+        self._mu = threading.Lock()
+
+    def slot(self, device):
+        key = str(device)
+        with self._mu:
+            s = self._slots.get(key)
+            if s is None:
+                s = self._slots[key] = _Slot()
+            return s
+
+    def clear(self):
+        with self._mu:
+            self._slots.clear()
+
+
+def _slot_property(name):
+    def get(self):
+        return getattr(self._slot(), name)
+
+    def set_(self, value):
+        setattr(self._slot(), name, value)
+    return property(get, set_)
+
+
+class DeviceStateMixin:
+    """Mixed into the two aggregator modules: `_arena`, `_plan`, `_plan_key`, `_guard`, `_forced_precision`, `_forced_key`,
+    `_graphs` are those of the slot of the device the module's parameters live on."""
+    _arena = _slot_property("arena")
+    _plan = _slot_property("plan")
+    _plan_key = _slot_property("plan_key")
+    _guard = _slot_property("guard")
+    _forced_precision = _slot_property("forced_precision")
+    _forced_key = _slot_property("forced_key")
+    _graphs = _slot_property("graphs")
+
+    def _init_device_state(self):
+        self.__dict__["_state"] = ModuleState()
+
+    def _device(self):
+        for p in self.parameters():
+            return p.device
+        return torch.device("cpu")
+
+    def _slot(self):
+        return self.__dict__["_state"].slot(self._device())
+
+    def _drop_device_state(self):
+        self.__dict__["_state"].clear()
+        self.__dict__.pop("_state_tensors", None)      # state_key re-walks the module tree
+
+
+REPLICA_ERROR = ("this module is an nn.DataParallel replica: the HIP aggregators run one process per GPU -- shard the batch with "
+                 "ms-nets_amd.dist (init_from_env / shard_indices / gather_disparities) instead of wrapping the model in "
+                 "nn.DataParallel (INTEGRATION.md section 3)")
 
 
 def ncdhw_to_ndhwc(x):
@@ -190,6 +273,19 @@ def conv3d_c8_ncdhw(x, wpk, scale, shift, co, relu=False):
     y = _new((n, d, h, w, co), x.device)
     check(_lib.load().msnet_conv3d_k3_c8_ncdhw_f16s(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(y), n, d, h, w, co, int(relu),
                                                     stream_ptr()), "msnet_conv3d_k3_c8_ncdhw_f16s")
+    return y
+
+
+def conv3d_c8_in(x, wpk, scale, shift, co, relu=False):
+    """First layer on a channels-last MODULE INPUT x [N,D,H,W,8] (VolumeBuilder(layout="ndhwc")) -> NDHWC [N,D,H,W,co]; split-fp16.
+    Same kernel as conv3d_k3 with Ci = 8, plus the fp16-range check of the module input (RangeGuard.INPUT)."""
+    x = require_gpu_f32(x, "x")
+    n, d, h, w, c = x.shape
+    if c != 8:
+        raise ValueError("conv3d_c8_in takes an 8-channel channels-last volume (got %d channels)" % c)
+    y = _new((n, d, h, w, co), x.device)
+    check(_lib.load().msnet_conv3d_k3_c8_in_f16s(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(y), n, d, h, w, co, int(relu),
+                                                 stream_ptr()), "msnet_conv3d_k3_c8_in_f16s")
     return y
 
 
@@ -355,7 +451,7 @@ class exact_tails:
 def _current_precision(module):
     """The module's sticky fp32 fallback belongs to the parameter state it was raised for: load_state_dict / .to() / any
     tracked in-place edit (state_key) lifts it."""
-    if module._forced_precision is not None and getattr(module, "_forced_key", None) != state_key(module):
+    if module._forced_precision is not None and module._forced_key != state_key(module):
         module._forced_precision = None
     return module._forced_precision or _default_precision
 
@@ -379,20 +475,39 @@ def _range_fallback(module, run, word):
         return run("fp32")
 
 
-def guarded_forward(module, run, graph_key=None):
-    """Shared by the two aggregators.  run(precision) -> output.  On the split-fp16 path the forward runs under a
+def guarded_forward(module, run, graph_key=None, use_arena_=True):
+    """Shared by the two aggregators.  run(precision) -> output.  Exclusive per (module, device): the slot's lock is held for
+    the whole forward, so a second thread calling the same module waits instead of sharing its activation buffers; an
+    nn.DataParallel replica is refused (REPLICA_ERROR).  On the split-fp16 path the forward runs under a
     RangeGuard; if an activation (or the input) left the fp16 range the result is discarded, a warning is issued and the
     forward is repeated on the exact fp32-input MFMA kernels with fp32 tails (_range_fallback: sticky for activations, per
     call for the input).
     graph_key (input address, shapes): with module.use_graph set, the forward is captured once per key as a HIP graph and
     replayed afterwards (_graphed_forward)."""
+    if getattr(module, "_is_replica", False):
+        raise RuntimeError(REPLICA_ERROR)
+    slot = module._slot()
+    with slot.lock:
+        # the arena's buffers are ordered by the stream of the forward that used them last: a forward arriving on ANOTHER
+        # stream (another thread) first waits for that one's kernels
+        stream = torch.cuda.current_stream()
+        if slot.last_event is not None and slot.last_stream != stream.cuda_stream:
+            stream.wait_event(slot.last_event)
+        out = _guarded_forward_locked(module, run, graph_key, use_arena_)
+        if slot.last_event is None:
+            slot.last_event = torch.cuda.Event()
+        slot.last_event.record(stream)
+        slot.last_stream = stream.cuda_stream
+        return out
+
+
+def _guarded_forward_locked(module, run_, graph_key, use_arena_):
     precision = _current_precision(module)
-    run_ = run
 
     def run(prec):                      # activations come from the module's arena (not when taps are handed out)
-        with use_arena(module._arena if module._use_arena else None):
+        with use_arena(module._arena if use_arena_ else None):
             return run_(prec)
-    if graph_key is not None and getattr(module, "use_graph", False) and module._use_arena:
+    if graph_key is not None and getattr(module, "use_graph", False) and use_arena_:
         return _graphed_forward(module, run_, graph_key)
     if precision != "split-fp16":
         with exact_tails():
@@ -400,8 +515,8 @@ def guarded_forward(module, run, graph_key=None):
     if not module.range_check:
         return run(precision)
     guard = module._guard
-    if guard is None or guard.flag.device != next(module.parameters()).device:
-        guard = module._guard = RangeGuard(next(module.parameters()).device)
+    if guard is None or guard.flag.device != module._device():
+        guard = module._guard = RangeGuard(module._device())
     with guard:
         out = run(precision)
     word = guard.word()
@@ -411,6 +526,18 @@ def guarded_forward(module, run, graph_key=None):
 
 
 MAX_GRAPHS_PER_MODULE = 4
+MAX_GRAPH_ARENA_BYTES = 32 << 30          # activation memory the captured graphs of one module (and device) may pin
+
+
+def _evict_graphs(graphs, skey):
+    """Make room for one more graph: entries captured for another parameter state (their key ends in another state_key) can
+    never be replayed again and go first; then oldest first while the cache holds MAX_GRAPHS_PER_MODULE entries or its arenas
+    pin more than MAX_GRAPH_ARENA_BYTES."""
+    for k in [k for k in graphs if k[-1] != skey]:
+        graphs.pop(k)
+    while graphs and (len(graphs) >= MAX_GRAPHS_PER_MODULE or
+                      sum(v["arena"].nbytes() for v in graphs.values() if v.get("arena")) > MAX_GRAPH_ARENA_BYTES):
+        graphs.pop(next(iter(graphs)))
 
 
 def _graphed_forward(module, run, graph_key):
@@ -423,9 +550,10 @@ def _graphed_forward(module, run, graph_key):
     another shape re-sizes the module's arena, never a captured graph's buffers.  The range guard stays on: its flag is
     cleared inside the graph and read after the replay; a trip drops the graphs and repeats the forward eagerly on fp32.
     Returns a copy of the graph's output buffer."""
-    graphs = module.__dict__.setdefault("_graphs", {})
+    graphs = module._graphs
     precision = _current_precision(module)
-    key = tuple(graph_key) + (precision, state_key(module))
+    skey = state_key(module)
+    key = tuple(graph_key) + (precision, skey)
     g = graphs.get(key)
     if g is None:
         module.use_graph = False
@@ -434,12 +562,14 @@ def _graphed_forward(module, run, graph_key):
         finally:
             module.use_graph = True
         if _current_precision(module) == precision:     # (else: the range guard moved the module to fp32)
-            if len(graphs) >= MAX_GRAPHS_PER_MODULE:
-                graphs.pop(next(iter(graphs)))
+            # a graph pins the packed weights and its own arena (~6 GB of activations per map at 960x544x192): graphs of an
+            # older parameter state can never be replayed again, so they go first; then the cache is bounded both by count
+            # and by the bytes its arenas hold (MAX_GRAPH_ARENA_BYTES), oldest first
+            _evict_graphs(graphs, skey)
             graphs[key] = {"graph": None}               # captured on the next call with this key
         return out
     if g["graph"] is None:
-        dev = next(module.parameters()).device
+        dev = module._device()
         guard = RangeGuard(dev) if precision == "split-fp16" and module.range_check else None
         arena = Arena()
 
@@ -477,7 +607,7 @@ def _graphed_forward(module, run, graph_key):
 
 
 def _with_arena(module, run, prec):
-    with use_arena(module._arena if module._use_arena else None):
+    with use_arena(module._arena):
         return run(prec)
 
 

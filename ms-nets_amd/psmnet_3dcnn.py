@@ -47,7 +47,7 @@ def _classif():
                          nn.Conv3d(32, 1, kernel_size=3, padding=1, stride=1, bias=False))
 
 
-class PSMNet_CostVolumeAggre(nn.Module):
+class PSMNet_CostVolumeAggre(hipops.DeviceStateMixin, nn.Module):
     def __init__(self, maxdisp, in_planes=64):
         """in_planes: channels of the input volume.  64 is the reference (a PSMNet feature-concat volume,
         psmnet_3dcnn.py:97); 8 (or 16) lets the aggregator take the matching-space volume directly, which the reference's
@@ -64,23 +64,15 @@ class PSMNet_CostVolumeAggre(nn.Module):
         self.classif2 = _classif()
         self.classif3 = _classif()
         net_init(self)
-        self._plan = None
-        self._plan_key = None
+        # per-device state (packed-weight plans, activation arena, range guard, captured graphs): hipops.ModuleState
+        self._init_device_state()
         self.range_check = os.environ.get("MSNET_RANGE_CHECK", "1") != "0"          # fp16-range guard of the split-fp16 kernels, see hipops.guarded_forward
-        self._forced_precision = None
-        self._guard = None
-        self._arena = hipops.Arena()      # activation buffers reused across forwards (hipops.Arena)
-        self._use_arena = True
         self.use_graph = False            # True: forwards are captured as HIP graphs per input buffer (hipops._graphed_forward)
 
     def invalidate_plans(self):
         """Drop the packed weights / folded BN constants; the next forward rebuilds them from the current parameters.
         Needed only after edits through `.data` (which leave no trace in the tensors' version counters)."""
-        self._plan = None
-        self._plan_key = None
-        self._forced_precision = None
-        self.__dict__.pop("_graphs", None)        # captured HIP graphs hold the old packed weights
-        self.__dict__.pop("_state_tensors", None)  # hipops.state_key re-walks the module tree
+        self._drop_device_state()          # plans, arenas, range guards, captured graphs (they hold the old packed weights)
 
     def _plans(self, precision):
         key = hipops.state_key(self)
@@ -155,6 +147,8 @@ class PSMNet_CostVolumeAggre(nn.Module):
         return cost1, cost2, cost3
 
     def _check(self, cost):
+        if getattr(self, "_is_replica", False):
+            raise RuntimeError(hipops.REPLICA_ERROR)
         if self.training:
             raise RuntimeError("PSMNet_CostVolumeAggre (HIP) is forward/inference only: call .eval() first")
         cost = hipops.require_gpu_f32(cost, "cost")
@@ -169,8 +163,9 @@ class PSMNet_CostVolumeAggre(nn.Module):
             with torch.no_grad():
                 _, _, cost3 = self._trunk(cost, taps, precision)
                 return hipops.trilinear_softargmin(cost3, (self.maxdisp, H, W))
-        self._use_arena = taps is None           # tapped activations are handed to the caller: fresh tensors
-        return hipops.guarded_forward(self, run, graph_key=(cost.data_ptr(), tuple(cost.shape), H, W) if taps is None else None)
+        # (tapped activations are handed to the caller: fresh tensors instead of the arena's)
+        return hipops.guarded_forward(self, run, graph_key=(cost.data_ptr(), tuple(cost.shape), H, W) if taps is None else None,
+                                      use_arena_=taps is None)
 
     def forward_all_heads(self, cost, out_hw=None):
         """(pred1, pred2, pred3) as the reference's training-mode return (psmnet_3dcnn.py:149-177)."""
@@ -179,5 +174,4 @@ class PSMNet_CostVolumeAggre(nn.Module):
         def run(precision):
             with torch.no_grad():
                 return tuple(hipops.trilinear_softargmin(c, (self.maxdisp, H, W)) for c in self._trunk(cost, None, precision))
-        self._use_arena = True
         return hipops.guarded_forward(self, run)

@@ -1050,3 +1050,90 @@ def test_range_fallback_scope(gpu):
         warnings.simplefilter("error")
         assert torch.equal(big(x), good)
     assert big._forced_precision is None
+
+
+def test_concurrent_forwards_from_two_threads(gpu):
+    """The reference wraps the model in nn.DataParallel (main_msnet.py:174): one Python THREAD per replica.  Two module
+    instances running forwards concurrently on two threads (here: on the one GPU, each on its own stream) must not hand each
+    other's activation buffers out -- results equal the serial ones bit for bit; two threads calling the SAME instance are
+    serialised by the module's per-device lock and also get the serial bits."""
+    import threading
+    G, P = _our_classes()
+    torch.manual_seed(11)
+    ma, mb = G(32).eval().cuda(), G(64).eval().cuda()
+    mp = P(32).eval().cuda()
+    xa, xb = torch.rand(2, 8, 16, 32, 48).cuda(), torch.rand(1, 8, 32, 16, 32).cuda()
+    xp = torch.rand(1, 64, 8, 12, 20).cuda()
+    ref = {"a": ma(xa).clone(), "b": mb(xb).clone(), "p": mp(xp).clone()}
+    torch.cuda.synchronize()
+    errs = []
+
+    def worker(name, m, x, reps):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(reps):
+                    out = m(x)
+                    s.synchronize()
+                    if not torch.equal(out, ref[name]):
+                        errs.append("%s: result differs from the serial forward" % name)
+                        return
+        except Exception as e:      # noqa: BLE001
+            errs.append("%s: %r" % (name, e))
+    ts = [threading.Thread(target=worker, args=("a", ma, xa, 20)), threading.Thread(target=worker, args=("b", mb, xb, 20)),
+          threading.Thread(target=worker, args=("p", mp, xp, 20)), threading.Thread(target=worker, args=("a", ma, xa, 20))]
+    [t.start() for t in ts]
+    [t.join(300) for t in ts]
+    assert not any(t.is_alive() for t in ts)
+    assert not errs, errs
+
+
+def test_data_parallel_wrapper_single_device_works_and_replicas_refuse(gpu):
+    """nn.DataParallel over ONE device calls the module itself (no replicas): the reference's wrapper line then just works.
+    A replica (what it creates for several devices) raises with the pointer to ms-nets_amd.dist."""
+    G, _ = _our_classes()
+    torch.manual_seed(12)
+    m = G(32).eval().cuda()
+    x = torch.rand(1, 8, 16, 16, 32).cuda()
+    ref = m(x).clone()
+    dp = torch.nn.DataParallel(m, device_ids=[0])
+    assert torch.equal(dp(x), ref)
+    rep = torch.nn.parallel.replicate(m, [0])[0]
+    with pytest.raises(RuntimeError, match="one process per GPU"):
+        rep(x)
+
+
+def test_forward_ndhwc_equals_forward(gpu):
+    """GCNet_CostVolumeAggre.forward_ndhwc on the channels-last volume == forward on the NCDHW volume, bit for bit (both
+    precisions; 8 and 16 input planes), and an out-of-range / NaN voxel of the channels-last input is caught by the first
+    layer's own check (RangeGuard.INPUT: that call falls back to fp32, the module stays on split-fp16)."""
+    from msnets_amd import hipops
+    G, _ = _our_classes()
+    for planes, shape in ((8, (2, 8, 16, 24, 40)), (16, (1, 16, 16, 16, 32))):
+        torch.manual_seed(21)
+        m = G(32, cbmv_in_planes=planes).eval().cuda()
+        x = torch.rand(shape).cuda()
+        xcl = x.permute(0, 2, 3, 4, 1).contiguous()
+        for prec in ("split-fp16", "fp32"):
+            hipops.set_default_precision(prec)
+            try:
+                assert torch.equal(m.forward_ndhwc(xcl), m(x)), (planes, prec)
+            finally:
+                hipops.set_default_precision("split-fp16")
+    torch.manual_seed(22)
+    m = G(32).eval().cuda()
+    x = torch.rand(1, 8, 16, 16, 32)
+    good = m(x.cuda()).clone()
+    bad = x.clone()
+    bad[0, 3, 5, 7, 9] = float("nan")
+    bcl = bad.permute(0, 2, 3, 4, 1).contiguous().cuda()
+    with pytest.warns(RuntimeWarning, match="module input"):
+        out = m.forward_ndhwc(bcl)
+    assert m._forced_precision is None                      # one bad sample does not move the module to fp32
+    assert torch.equal(m.forward_ndhwc(x.permute(0, 2, 3, 4, 1).contiguous().cuda()), good)
+    big = x.clone()
+    big[0, 1, 2, 3, 4] = 5e4
+    with pytest.warns(RuntimeWarning, match="module input"):
+        m.forward_ndhwc(big.permute(0, 2, 3, 4, 1).contiguous().cuda())
+    with pytest.raises(ValueError):
+        m.forward_ndhwc(x.cuda())                           # an NCDHW tensor is not a channels-last volume of 8 planes

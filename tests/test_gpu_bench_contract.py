@@ -32,8 +32,25 @@ def test_bench_json_contract(gpu):
     assert r["bound"] in ("mfma", "hbm") and r["unit"] in ("TFLOP/s", "GB/s") and r["launches"] >= 2
     assert 0.05 < r["frac"] < 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["traffic"] is None or r["traffic"] > 1e9
+    # the dominant family is the one with the largest total time per step, and the line carries the top three
+    ks = r["kernels"]
+    assert 1 <= len(ks) <= 3 and ks[0]["family"] == r["family"] and r["dominant_by"].startswith("largest total kernel time")
+    assert all(ks[i]["ms_per_step"] >= ks[i + 1]["ms_per_step"] * 0.8 for i in range(len(ks) - 1))      # (timed region vs post-pass)
+    for k in ks:
+        assert k["bound"] in ("mfma", "hbm") and 0 < k["frac"] < 1 and abs(k["frac"] - k["achieved"] / k["peak"]) < 1e-9
+        assert k["timed_in"] in ("timed region", "post-pass") and 0 < k["time_share_of_kernels"] < 1
+    assert abs(r["frac"] - ks[0]["frac"]) < 1e-9 and r["timed_in"] == "timed region"
+    # what the headline depends on besides the code
+    assert d["config"]["weights"].startswith("net_init") and d["config"]["range_guard_tripped"] is False
+    p = d["power"]
+    assert set(p) >= {"power_w", "sclk_mhz", "samples", "source"}
+    if p["power_w"] is not None:
+        assert 100 < p["power_w"] < 1500
+    if p["sclk_mhz"] is not None:
+        assert 100 < p["sclk_mhz"] < 2600
     v = d["roofline_volume"]
-    assert v["bound"] == "hbm" and v["unit"] == "GB/s" and abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-9
+    assert v["bound"] in ("hbm", "valu-issue") and v["priced_against"] == "hbm" and v["unit"] == "GB/s"
+    assert abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-9 and v["hbm_frac"] == v["frac"]
     assert abs(v["algorithmic_bytes_per_map"] - (8 * 96 * 272 * 480 * 4 + 2 * 292 * 500)) < 1
     assert 0 < d["step_ms"]["p10"] <= d["step_ms"]["median"] <= d["step_ms"]["p90"]
 
@@ -103,3 +120,37 @@ def test_bench_roofline_step_and_profile_facts(gpu):
     assert abs(rs["frac"] - rs["achieved"] / rs["peak"]) < 1e-9
     if r["frac_rocprof"] is not None:
         assert abs(r["frac_rocprof"] - r["frac"]) < 0.1 and 1.0 < r["sustained_clock_ghz"] < 2.6
+
+
+WD_SHARE = 2 * 27 * 32 * 32 * 96 * 272 * 480 / 2.1307e12          # conv3dbn_2's share of the 19 convs' FLOPs at config #2
+
+
+def test_roofline_step_is_per_map_at_batch_2(gpu):
+    """A launch covers the B maps of the batch: the Winograd FLOPs that set `mfmas_per_algorithmic_product` are per MAP, so the
+    value at --batch-per-gpu 2 equals the batch-1 value (3 - 0.325 = 2.675), never below 2."""
+    d = _run("--no-cpu-baseline", "--no-extras", "--batch-per-gpu", "2")
+    rs = d["roofline_step"]
+    assert 2.0 <= rs["mfmas_per_algorithmic_product"] <= 3.0
+    assert abs(rs["mfmas_per_algorithmic_product"] - (3.0 - WD_SHARE)) < 2e-3
+    assert abs(rs["winograd_flops_per_map"] - 2 * 27 * 32 * 32 * 96 * 272 * 480) < 1e6
+    assert abs(rs["peak"] - 2500.0 / rs["mfmas_per_algorithmic_product"]) < 1e-6 and 0 < rs["frac"] < 1
+    assert abs(rs["achieved"] - 2 * rs["flops_per_map"] / (d["ms_per_step"] * 1e-3) / 1e12) < 1e-6 * rs["achieved"]
+
+
+def test_cfg3_line_carries_roofline_step(gpu):
+    d = _run("--no-cpu-baseline", "--no-extras", "--workload", "cfg3")
+    rs = d["roofline_step"]
+    assert abs(rs["flops_per_map"] - 1.0098e12) < 2e9                      # SURVEY 8(a) a16: 505 GMAC
+    assert 2.0 < rs["mfmas_per_algorithmic_product"] < 3.0 and 0 < rs["frac"] < 1
+    assert d["roofline"]["kernels"] and d["roofline"]["family"] == d["roofline"]["kernels"][0]["family"]
+
+
+def test_bench_world2_on_one_gpu(gpu):
+    """world_size 2 on the ONE GPU of this box: `--dist-backend gloo` lets both ranks use cuda:0 (RCCL would refuse), so every
+    world > 1 branch of bench.py / ms-nets_amd/dist.py -- per-rank sharding of an UNEVEN batch, padding + permutation of the
+    gathered device tensors, the ordering assert, the max-over-ranks of the timing -- runs on hardware.  Functional only."""
+    d = _run("--gpus", "2", "--dist-backend", "gloo", "--no-cpu-baseline", "--no-extras", "--workload", "cfg1", "--global-batch", "3")
+    assert d["n_gpus"] == 2 and d["config"]["world_size"] == 2 and d["config"]["global_batch"] == 3
+    assert d["config"]["dist_backend"] == "gloo" and d["config"]["ranks_per_device"] == 2
+    assert d["config"]["collective"].startswith("gloo") and d["value"] > 0
+    assert d["config"]["launcher"].startswith("bench.py self-launch")

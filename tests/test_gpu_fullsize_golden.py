@@ -11,6 +11,15 @@ Gates per case (every one can fail on its own):
       kappa_i = sum_d |d - disp_i| p_d (first-order sensitivity of pixel i's soft-argmin to a logit perturbation) computed
       in fp64 from the HIP logits.  The tolerance is built from the G1 BOUND (5e-6 relative), never from the measured error.
 
+  N   (round 4; recipes.ALT_CASES) against the reference's OWN fp32 noise floor: tests/golden/fullsize_<case>_alt.npz hold the
+      unmodified reference forward of the same weights and input under other summation orders (1 thread instead of 8; oneDNN
+      off).  p99 / p99.9 / max of |HIP - reference| must stay within NOISE_FACTOR x the same statistic of
+      |reference_alt - reference| (the larger of the variants), and the fraction of pixels beyond the flat 1e-3 within
+      NOISE_FACTOR x the reference's own fraction (+ 0.1 point).  The exact-fp32 MFMA path is measured next to the default
+      split-fp16 path.
+  U   gcnet_cfg2_ms_unimodal: the softmax is unimodal AT THE PLANTED DISPARITY on > 80 % of the map (kappa <= 1 there); a flat
+      1e-3 is asserted over the WHOLE map, and >= 85 % of the pixels must regress to within half a pixel of the planted value.
+
 "Well conditioned" = random-init MS-GCNet (logits within +-6, kappa <= 54): there F holds for the whole map.  With a
 multi-modal peaky softmax (logits ~ +-100, kappa up to 95) a relative logit difference of 1e-6 -- fp32 summation-order noise
 -- already moves a badly conditioned pixel by 1e-2; there F is asserted on the pixels with kappa_i <= KAPPA_FLAT (and the
@@ -31,6 +40,16 @@ DISP_TOL = 1e-3
 TAP_TOL = 5e-6          # relative to the layer's max magnitude (the reference's samples); measured <= 2.3e-6
 G1_BOUND = 5e-6         # bound on the relative logit error the K gate is built from (== TAP_TOL on the logit tap)
 KAPPA_FLAT = 1.0        # pixels at least this well conditioned must meet the flat 1e-3 in every case
+NOISE_FACTOR = {"p99": 2.0, "p99.9": 2.0, "max": 3.0}      # gate N (the max of ~5e5 pixels is an extreme-value statistic: looser)
+# fraction of the map within a flat 1e-3: the value measured in round 3 (profiles/r03x_parity_errors.txt) minus half a point
+FRAC_FLAT_MIN = {"gcnet_cfg2": 0.995, "gcnet_cfg5": 0.995, "gcnet_cfg2_ms_unimodal": 0.995, "gcnet_cfg2_peaky": 0.9897,
+                 "gcnet_cfg2_ms_peaky": 0.9946, "gcnet_cfg5_peaky": 0.9936, "psmnet_cfg3": 0.9918, "psmnet_cfg3_peaky": 0.9743}
+
+
+def _stats(e):
+    f = e.flatten().float()
+    q = lambda x: float(f.kthvalue(max(1, int(x * f.numel())))[0])      # noqa: E731
+    return {"p99": q(0.99), "p99.9": q(0.999), "max": float(f.max()), "beyond": float((f > DISP_TOL).float().mean())}
 
 
 def _classes():
@@ -78,7 +97,7 @@ def test_fullsize_vs_reference(gpu, name):
     disp_t = model(xg, taps=taps).cpu()                      # un-fused tail: logits materialised
     H, W = recipes.out_hw(case)
     # ---- T: sampled activations vs the reference's samples
-    worst_tap = 0.0
+    worst_tap, logit_rel = 0.0, 0.0
     for key in gold.files:
         if not key.startswith("tap_"):
             continue
@@ -87,6 +106,8 @@ def test_fullsize_vs_reference(gpu, name):
         g = gold[key]
         rel = float(np.abs(s - g).max() / max(1.0, float(np.abs(g).max())))
         worst_tap = max(worst_tap, rel)
+        if t in ("deconv5", "cost3"):
+            logit_rel = rel
         print("%s: tap %-11s rel err %.2e (max|ref| %.3g)" % (name, t, rel, float(np.abs(g).max())))
         assert rel <= TAP_TOL, (t, rel)
     # ---- logits -> kappa
@@ -122,7 +143,47 @@ def test_fullsize_vs_reference(gpu, name):
         assert float(err[well].max()) <= DISP_TOL, "flat gate on the well-conditioned pixels"
     if not case.get("peaky") and case["model"] == "gcnet":
         assert float(err.max()) <= DISP_TOL, "flat gate"
-    assert frac_flat >= 0.95
+    assert frac_flat >= FRAC_FLAT_MIN[name], (frac_flat, FRAC_FLAT_MIN[name])
+    # ---- U: the unimodal case -- flat 1e-3 over the whole map, softmax peaked where the disparity was planted
+    if case.get("unimodal"):
+        from msnets_amd import synthetic
+        n, c, d, h, w = case["in_shape"]
+        rows = synthetic.stereo_pair(h, w, d, seed=case["seed"])[2]
+        truth = torch.from_numpy(np.repeat(2.0 * rows, 2)).float().view(1, -1, 1)
+        at_peak = float(((disp - truth).abs() <= 0.5).float().mean())
+        print("%s: kappa <= 1 on %.1f%% of the map, |disp - planted| <= 0.5 px on %.1f%%, max|disp - reference| %.3e over the WHOLE map"
+              % (name, 100 * float(well.float().mean()), 100 * at_peak, float(err.max())))
+        assert float(well.float().mean()) > 0.80 and at_peak > 0.85
+        assert float(err.max()) <= DISP_TOL, "flat gate over the whole map (unimodal case)"
+    # ---- N: the reference's own summation-order noise floor
+    if name in recipes.ALT_CASES:
+        from msnets_amd import hipops
+        alt = np.load(os.path.join(GOLD, "fullsize_%s_alt.npz" % name))
+        assert str(alt["state_sha256"]) == str(gold["state_sha256"])
+        variants = [k[5:] for k in alt.files if k.startswith("disp_")]
+        floor = {}
+        for v in variants:
+            st = _stats((torch.from_numpy(alt["disp_" + v]) - ref).abs())
+            print("%s: reference[%s] vs reference: p99 %.2e p99.9 %.2e max %.2e, %.3f%% beyond 1e-3" % (
+                name, v, st["p99"], st["p99.9"], st["max"], 100 * st["beyond"]))
+            floor = {k: max(floor.get(k, 0.0), x) for k, x in st.items()}
+        tapname = "deconv5" if case["model"] == "gcnet" else "cost3"
+        g = gold["tap_" + tapname]
+        lfloor = max(float(np.abs(alt["tap_%s_%s" % (tapname, v)] - g).max()) for v in variants) / max(1.0, float(np.abs(g).max()))
+        hipops.set_default_precision("fp32")
+        try:
+            d32 = model(xg).cpu()
+        finally:
+            hipops.set_default_precision("split-fp16")
+        for label, e in (("HIP split-fp16", err), ("HIP exact fp32", (d32 - ref).abs())):
+            st = _stats(e)
+            print("%s: %s vs reference: p99 %.2e p99.9 %.2e max %.2e, %.3f%% beyond 1e-3  |  x the reference's own floor: "
+                  "p99 %.2f p99.9 %.2f max %.2f" % (name, label, st["p99"], st["p99.9"], st["max"], 100 * st["beyond"],
+                                                    st["p99"] / floor["p99"], st["p99.9"] / floor["p99.9"], st["max"] / floor["max"]))
+            for k, fac in NOISE_FACTOR.items():
+                assert st[k] <= fac * floor[k] + 1e-5, (label, k, st[k], floor[k])
+            assert st["beyond"] <= NOISE_FACTOR["p99"] * floor["beyond"] + 1e-3, (label, st["beyond"], floor["beyond"])
+        print("%s: logit samples, relative: reference-vs-reference %.2e, HIP split-fp16 vs reference %.2e" % (name, lfloor, logit_rel))
     # ---- the MS-volume case also runs end to end from the two images through the HIP volume build
     if pair is not None:
         from msnets_amd import cbmv_generator as cg
@@ -133,6 +194,9 @@ def test_fullsize_vs_reference(gpu, name):
               % (name, float(e2e.max()), 100 * float((e2e <= DISP_TOL).float().mean())))
         # the likelihood channels differ by <= 2e-6 (GPU expf vs glibc expf): an input perturbation the K gate has no term
         # for, so only the well-conditioned pixels and the map-level fraction are asserted
+        # (measured in round 3: 99.96 % of the map within 1e-3, 8.4e-5 on the well-conditioned pixels)
         if bool(well.any()):
-            assert float(e2e[well].max()) <= 2 * DISP_TOL
-        assert float((e2e <= DISP_TOL).float().mean()) >= 0.85
+            assert float(e2e[well].max()) <= 2e-4
+        assert float((e2e <= DISP_TOL).float().mean()) >= 0.995
+        if case.get("unimodal"):
+            assert float(e2e.max()) <= DISP_TOL, "flat gate, end to end from the images (unimodal case)"

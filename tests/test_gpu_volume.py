@@ -186,3 +186,52 @@ def test_volume_errors(gpu):
         mtc.census(l, r, 8, 4)
     with pytest.raises(ValueError):
         mtc.zsad(l, r[:, :-1].copy(), 8, 5)
+
+
+# ---- round 4: the channels-last build (msnet_build_volume_ndhwc) ------------------------------------------------------------
+@pytest.mark.parametrize("Hh,Wh,nd,seed", [(32, 64, 16, 0), (20, 70, 8, 1), (37, 129, 32, 2), (16, 200, 96, 3), (5, 33, 24, 4),
+                                           (64, 63, 40, 5)])
+def test_channels_last_volume_is_the_ncdhw_volume_transposed(gpu, Hh, Wh, nd, seed):
+    """VolumeBuilder(layout='ndhwc') [D',H',W',8] == the NCDHW build [8,D',H',W'] permuted, bit for bit (ragged widths, row
+    ends inside a 64-pixel segment, D' = 8 .. 96, both register-array instantiations)."""
+    from msnets_amd import cbmv_generator as cg, synthetic
+    left, right, _ = synthetic.stereo_pair(Hh, Wh, nd, seed=seed)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    ref = cg.build_ms_volume(l, r, nd)
+    vb = cg.VolumeBuilder(l.shape[0], l.shape[1], nd, l.device, layout="ndhwc")
+    assert vb.native_cl
+    got = vb(l, r)
+    assert got.shape == (nd, Hh, Wh, 8)
+    assert torch.equal(got, ref.permute(1, 2, 3, 0).contiguous())
+    out = torch.full_like(got, float("nan"))                 # every element of a caller's buffer is written
+    vb(l, r, out=out)
+    assert torch.equal(out, got)
+
+
+def test_channels_last_volume_full_size(gpu):
+    """config #2's shape, and the extreme images (flat / checkerboard: sentinel-only rows, NCC's non-finite branch)."""
+    from msnets_amd import cbmv_generator as cg, synthetic
+    left, right, _ = synthetic.stereo_pair(272, 480, 96, seed=7)
+    rng = np.random.default_rng(0)
+    flat = np.zeros_like(left)
+    flat[10:-10, 10:-10] = 77
+    chk = np.zeros_like(left)
+    chk[10:-10, 10:-10] = ((np.add.outer(np.arange(272), np.arange(480)) & 1) * 255).astype(np.uint8)
+    noise = np.zeros_like(left)
+    noise[10:-10, 10:-10] = rng.integers(0, 256, size=(272, 480))
+    for a, b in ((left, right), (flat, flat), (chk, np.roll(chk, 1, axis=1)), (noise, flat)):
+        l, r = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+        ref = cg.build_ms_volume(l, r, 96)
+        got = cg.build_ms_volume(l, r, 96, layout="ndhwc")
+        assert torch.equal(got, ref.permute(1, 2, 3, 0).contiguous())
+
+
+def test_channels_last_layout_falls_back_for_other_windows(gpu):
+    """Parameters the channels-last kernel does not take (here a 9x9 census window) are built NCDHW and converted: same API."""
+    from msnets_amd import cbmv_generator as cg, synthetic
+    left, right, _ = synthetic.stereo_pair(24, 48, 16, seed=3)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    vb = cg.VolumeBuilder(l.shape[0], l.shape[1], 16, l.device, params=dict(censw=9), layout="ndhwc")
+    assert not vb.native_cl
+    ref = cg.build_ms_volume(l, r, 16, params=dict(censw=9))
+    assert torch.equal(vb(l, r), ref.permute(1, 2, 3, 0).contiguous())
