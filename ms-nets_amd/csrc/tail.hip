@@ -446,15 +446,21 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict
 // out[P+1].  A workgroup multiplies 8 x 32 input voxels per slice (origin h0-1, w0-1) and finishes the inner 6 x 30 outputs.
 __global__ __launch_bounds__(256) void conv_cout1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, float wsc,
                                                               const float* __restrict__ add, float* __restrict__ y, int N,
-                                                              int D, int H, int W, int nth, int ntw) {
+                                                              int D, int H, int W, int nth, int ntw, int nseg, int dseg) {
+    // A workgroup walks the depth slices of ONE SEGMENT [o0, o1) of output slices of its (h, w) tile: the (h, w) tiles alone
+    // are too few to fill the chip on quarter-resolution volumes (136 x 240: 184 tiles for 256 CUs, each a serial chain of 48
+    // slices with four barriers per slice -- 2.0 TB/s).  A segment reads its input slices o0-1 .. o1 (one halo slice per side).
     constexpr int CI = 32, TH = 8, TW = 32, UH = 6, UW = 30, PS = CI + 4, TS = 33, NT = 256;
     __shared__ __attribute__((aligned(16))) float xs[TH * TW * PS];
     float* const ts = xs;                               // partials reuse the slice buffer (TS <= PS)
     SliceStage<CI, TH, TW, NT> stg;
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tw = bid % ntw; bid /= ntw;
-    const int th = bid % nth;
-    const int n = bid / nth;
+    const int th = bid % nth; bid /= nth;
+    const int seg = bid % nseg;
+    const int n = bid / nseg;
+    const int o0 = seg * dseg, o1 = min(D, o0 + dseg);  // output slices of this workgroup
+    const int p_first = max(o0 - 1, 0);                 // first input slice it needs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, kq = lane >> 5;
     const int h0 = th * UH, w0 = tw * UW;               // first output row / column of the tile; inputs start one before
@@ -475,8 +481,8 @@ __global__ __launch_bounds__(256) void conv_cout1_mfma_kernel(const float* __res
     }
 
     float r1 = 0.f, r0 = 0.f;
-    stg.load(x, (size_t)n * D * H * W, H, W, h0 - 1, w0 - 1, tid, true);
-    for (int P = 0; P <= D; ++P) {
+    stg.load(x, ((size_t)n * D + p_first) * H * W, H, W, h0 - 1, w0 - 1, tid, true);
+    for (int P = p_first; P <= o1; ++P) {               // out[P-1] = q0(P-2) + q1(P-1) + q2(P): same additions as one pass over all of D
         float q[3] = {0.f, 0.f, 0.f};
         if (P < D) {
             __syncthreads();                            // slice P-1: gathers done
@@ -510,7 +516,7 @@ __global__ __launch_bounds__(256) void conv_cout1_mfma_kernel(const float* __res
 #pragma unroll
                 for (int e = 0; e < 16; ++e) dst[(e & 3) + 8 * (e >> 2)] = a0[e] + a1[e] * (1.f / 2048.f);
             }
-            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0 - 1, w0 - 1, tid, P + 1 < D);   // after the MFMA phase (registers)
+            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0 - 1, w0 - 1, tid, P + 1 < D && P + 1 <= o1);   // after the MFMA phase (registers)
             __syncthreads();
             if (live) {
                 const float* t0 = ts + (r * 32 + c) * TS;
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(256) void conv_cout1_mfma_kernel(const float* __res
                         for (int kw = 0; kw < 3; ++kw) q[kd] += t0[(kh * 32 + kw) * TS + kd * 9 + kh * 3 + kw];
             }
         }
-        if (P >= 1 && live) {
+        if (P - 1 >= o0 && live) {
             const size_t idx = (((size_t)n * D + (P - 1)) * H + h) * W + wq;
             float v = (r1 + q[2]) * wsc;
             if (add) v += add[idx];
@@ -684,6 +690,17 @@ extern "C" int msnet_deconv3d_cout1(const float* x, const float* w, float bias, 
     return check_launch("msnet_deconv3d_cout1");
 }
 
+static int num_cus_tail() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess && p.multiProcessorCount > 0)
+                ? p.multiProcessorCount : 256;
+    }
+    return n;
+}
+
 extern "C" int msnet_conv3d_k3_cout1(const float* x, const float* w, float wscale, const float* add, float* y, int N, int D, int H,
                                      int W, int Ci, msnet_stream_t stream) {
     if (!x || !w || !y) return fail("msnet_conv3d_k3_cout1: null pointer");
@@ -698,8 +715,16 @@ extern "C" int msnet_conv3d_k3_cout1(const float* x, const float* w, float wscal
                            W, nth, ntw);
     } else {
         const int nth = cdiv(H, 6), ntw = cdiv(W, 30);
-        hipLaunchKernelGGL(conv_cout1_mfma_kernel, dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, wscale, add, y, N, D, H, W,
-                           nth, ntw);
+        // depth segments: enough workgroups for ~3 per CU (37 KB of LDS each: four fit), segments of at least 6 slices (each
+        // costs two halo slices of extra reads)
+        const long tiles = (long)N * nth * ntw;
+        int nseg = (int)((3L * num_cus_tail() + tiles - 1) / tiles);
+        nseg = nseg < 1 ? 1 : nseg;
+        if (nseg > cdiv(D, 6)) nseg = cdiv(D, 6);
+        const int dseg = cdiv(D, nseg);
+        nseg = cdiv(D, dseg);
+        hipLaunchKernelGGL(conv_cout1_mfma_kernel, dim3((unsigned)(tiles * nseg)), dim3(256), 0, s, x, w, wscale, add, y, N, D, H, W,
+                           nth, ntw, nseg, dseg);
     }
     return check_launch("msnet_conv3d_k3_cout1");
 }

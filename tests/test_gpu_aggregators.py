@@ -372,7 +372,9 @@ def test_deconv3d_layer_split_fp16(gpu, hiplib, ci, co, dims, relu, use_res, dir
     assert err < 5e-6
 
 
-@pytest.mark.parametrize("dims,use_add", [((1, 5, 9, 33), False), ((2, 4, 8, 40), True), ((1, 1, 3, 5), False)])
+# (round 4: the kernel walks depth SEGMENTS -- 13, 20 and 48 slices give uneven last segments and 2 .. 8 segments per tile)
+@pytest.mark.parametrize("dims,use_add", [((1, 5, 9, 33), False), ((2, 4, 8, 40), True), ((1, 1, 3, 5), False),
+                                          ((1, 13, 7, 31), True), ((2, 20, 6, 30), False), ((1, 48, 12, 61), True)])
 def test_conv3d_cout1_head(gpu, dims, use_add):
     from msnets_amd import hipops
     g = torch.Generator().manual_seed(5)

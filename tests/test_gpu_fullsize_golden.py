@@ -14,7 +14,7 @@ Gates per case (every one can fail on its own):
   N   (round 4; recipes.ALT_CASES) against the reference's OWN fp32 noise floor: tests/golden/fullsize_<case>_alt.npz hold the
       unmodified reference forward of the same weights and input under other summation orders (1 thread instead of 8; oneDNN
       off).  p99 / p99.9 / max of |HIP - reference| must stay within NOISE_FACTOR x the same statistic of
-      |reference_alt - reference| (the larger of the variants), and the fraction of pixels beyond the flat 1e-3 within
+      |reference_alt - reference| (the larger of the variants) or within the flat 1e-3, and the fraction of pixels beyond the flat 1e-3 within
       NOISE_FACTOR x the reference's own fraction (+ 0.1 point).  The exact-fp32 MFMA path is measured next to the default
       split-fp16 path.
   U   gcnet_cfg2_ms_unimodal: the softmax is unimodal AT THE PLANTED DISPARITY on > 80 % of the map (kappa <= 1 there); a flat
@@ -180,8 +180,8 @@ def test_fullsize_vs_reference(gpu, name):
             print("%s: %s vs reference: p99 %.2e p99.9 %.2e max %.2e, %.3f%% beyond 1e-3  |  x the reference's own floor: "
                   "p99 %.2f p99.9 %.2f max %.2f" % (name, label, st["p99"], st["p99.9"], st["max"], 100 * st["beyond"],
                                                     st["p99"] / floor["p99"], st["p99.9"] / floor["p99.9"], st["max"] / floor["max"]))
-            for k, fac in NOISE_FACTOR.items():
-                assert st[k] <= fac * floor[k] + 1e-5, (label, k, st[k], floor[k])
+            for k, fac in NOISE_FACTOR.items():      # (an error inside the flat 1e-3 needs no noise-floor argument)
+                assert st[k] <= max(fac * floor[k], DISP_TOL), (label, k, st[k], floor[k])
             assert st["beyond"] <= NOISE_FACTOR["p99"] * floor["beyond"] + 1e-3, (label, st["beyond"], floor["beyond"])
         print("%s: logit samples, relative: reference-vs-reference %.2e, HIP split-fp16 vs reference %.2e" % (name, lfloor, logit_rel))
     # ---- the MS-volume case also runs end to end from the two images through the HIP volume build
