@@ -74,74 +74,56 @@ def psmnet_flops(H, W, D):
     return 2.0 * mac
 
 
-class PowerSampler:
-    """Package power and shader clock DURING the timed region, read from the amdgpu hwmon / sysfs files of the device by a side
-    thread (plain file reads -- no HIP call, no rocm-smi process): the headline is power-limited, so the line says
-    at how many watts and at which granted clock it was measured.  Every field is None where the box does not expose the file."""
+class PowerMeter:
+    """Package power and granted shader clock OVER the timed region.
+    power_w  : energy counter of the package (rocm_smi_lib rsmi_dev_energy_count_get: the SMU's accumulator, 15.3 uJ units)
+               read right before and right after the region -> joules / seconds.  Reads sysfs through the library: no HIP
+               call, no child process.  (The instantaneous hwmon files of this pool -- power1_input, freq1_input, pp_dpm_sclk --
+               read IDLE values while the GPU is loaded, profiles/r04_power_probe.txt, so they are not used.)
+    sclk_mhz : two one-thread kernels (msnet_clock_probe) on the step's stream, the first in front of the first step and the
+               second behind the last: shader-clock ticks (s_memtime) / constant-100-MHz ticks (s_memrealtime) between them.
+    Every field is None where the box offers no such source."""
 
-    def __init__(self, index=0, period_s=0.004):
-        import glob
-        self.period, self.samples, self._stop, self._thr = period_s, [], False, None
-        self.power_file = self.sclk_file = None
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device"))
-        cards = [c for c in cards if os.path.exists(os.path.join(c, "pp_dpm_sclk")) or glob.glob(os.path.join(c, "hwmon/hwmon*/power1_*"))]
-        if index < len(cards):
-            c = cards[index]
-            for name in ("power1_average", "power1_input"):
-                f = glob.glob(os.path.join(c, "hwmon/hwmon*/" + name))
-                if f:
-                    self.power_file = f[0]
+    def __init__(self, index, dev):
+        import ctypes
+        self.ct, self.index, self.rsmi, self.e0, self.t0 = ctypes, index, None, None, None
+        for cand in ("/opt/rocm/lib/librocm_smi64.so", "librocm_smi64.so"):
+            try:
+                lib = ctypes.CDLL(cand)
+                if lib.rsmi_init(0) == 0:
+                    self.rsmi = lib
                     break
-            f = glob.glob(os.path.join(c, "hwmon/hwmon*/freq1_input"))
-            self.sclk_file = f[0] if f else None
-            self.dpm_file = os.path.join(c, "pp_dpm_sclk")
+            except (OSError, AttributeError):
+                pass
+        self.clk = torch.zeros(4, dtype=torch.int64, device=dev)
 
-    @staticmethod
-    def _read(path):
-        try:
-            with open(path) as f:
-                return f.read()
-        except Exception:
+    def _energy_j(self):
+        if self.rsmi is None:
             return None
-
-    def _sample(self):
-        w = mhz = None
-        t = self._read(self.power_file) if self.power_file else None
-        if t:
-            w = float(t) * 1e-6                                   # microwatts
-        t = self._read(self.sclk_file) if self.sclk_file else None
-        if t:
-            mhz = float(t) * 1e-6                                 # Hz
-        elif getattr(self, "dpm_file", None):
-            t = self._read(self.dpm_file)
-            for ln in (t or "").splitlines():
-                if ln.rstrip().endswith("*"):
-                    mhz = float(ln.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
-        return w, mhz
+        ct = self.ct
+        e, res, ts = ct.c_uint64(), ct.c_float(), ct.c_uint64()
+        if self.rsmi.rsmi_dev_energy_count_get(self.index, ct.byref(e), ct.byref(res), ct.byref(ts)) != 0:
+            return None
+        return e.value * res.value * 1e-6
 
     def start(self):
-        import threading
-        if not (self.power_file or self.sclk_file):
-            return self
-
-        def loop():
-            while not self._stop:
-                self.samples.append(self._sample())
-                time.sleep(self.period)
-        self._thr = threading.Thread(target=loop, daemon=True)
-        self._thr.start()
-        return self
+        from msnets_amd import _lib
+        self.e0, self.t0 = self._energy_j(), time.perf_counter()
+        _lib.check(_lib.load().msnet_clock_probe(_lib.ptr(self.clk), _lib.stream_ptr()), "msnet_clock_probe")
 
     def stop(self):
-        self._stop = True
-        if self._thr is not None:
-            self._thr.join(1.0)
-        ws = [w for w, _ in self.samples if w]
-        ms = [m for _, m in self.samples if m]
-        return {"power_w": float(np.mean(ws)) if ws else None, "power_w_max": float(np.max(ws)) if ws else None,
-                "sclk_mhz": float(np.mean(ms)) if ms else None, "samples": len(self.samples),
-                "source": ("amdgpu hwmon sysfs, side thread, every %.0f ms of the timed region" % (1e3 * self.period)
-                           if self.samples else "not exposed on this box")}
+        """Call behind the region's closing synchronize."""
+        from msnets_amd import _lib
+        _lib.check(_lib.load().msnet_clock_probe(_lib.ptr(self.clk[2:]), _lib.stream_ptr()), "msnet_clock_probe")
+        torch.cuda.synchronize()
+        e1, t1 = self._energy_j(), time.perf_counter()
+        c = [int(v) for v in self.clk.cpu()]
+        ticks, real = c[2] - c[0], (c[3] - c[1]) / 1e8
+        return {"power_w": (e1 - self.e0) / (t1 - self.t0) if self.e0 is not None and e1 is not None and t1 > self.t0 else None,
+                "energy_j_per_map": None,
+                "sclk_mhz": ticks / real / 1e6 if real > 0 and ticks > 0 else None,
+                "source": "power: package energy counter (rocm_smi_lib) over the timed region; clock: s_memtime / s_memrealtime "
+                          "between two one-thread kernels around it"}
 
 
 def _source_sha(*names):
@@ -446,11 +428,11 @@ def main():
     dom_prefix = None if args.verbose else ",".join(timed_families + VOLUME_FAMILIES)
     _lib.prof_enable(not args.no_kernel_timing, dom_prefix)
     step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    sampler = PowerSampler(local)
+    meter = PowerMeter(local, dev) if rank == 0 else None
     msdist.barrier()
     torch.cuda.synchronize()
-    if rank == 0:
-        sampler.start()
+    if meter:
+        meter.start()
     t0 = time.perf_counter()
     step_ev[0].record()
     for k in range(args.steps):
@@ -459,7 +441,9 @@ def main():
     torch.cuda.synchronize()
     msdist.barrier()
     dt = time.perf_counter() - t0
-    power = sampler.stop() if rank == 0 else None
+    power = meter.stop() if meter else None
+    if power and power["power_w"] is not None:
+        power["energy_j_per_map"] = power["power_w"] * dt / (args.steps * B)
     _lib.prof_enable(False)
     prof = _lib.prof_collect()
     all_timed = dom_prefix is None and not args.no_kernel_timing

@@ -31,6 +31,7 @@ SIGNATURES = {
     "msnet_peak_mfma_f16": (ctypes.c_double, [P, c_int, P]),
     "msnet_peak_mfma_f16_16x16": (ctypes.c_double, [P, c_int, P]),
     "msnet_peak_mfma_f16_rand": (ctypes.c_double, [P, c_int, c_int, P]),
+    "msnet_clock_probe": (c_int, [P, P]),
     "msnet_census": (c_int, [P, P, P, P, c_int, c_int, c_int, c_int, P]),
     "msnet_census_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "msnet_ncc": (c_int, [P, P, P, c_int, c_int, c_int, c_int, P]),

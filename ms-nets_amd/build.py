@@ -19,6 +19,14 @@ SOURCES = [
     ("peaks.hip", []),
     ("conv3d.hip", []),
     ("conv3d_f16s.hip", []),
+    ("conv3d_f16s_ws_s2.hip", []),
+    ("conv3d_f16s_ws_c16.hip", []),
+    ("conv3d_f16s_ws_co64.hip", []),
+    ("conv3d_f16s_ws_co32.hip", []),
+    ("conv3d_f16s_c8.hip", []),
+    ("conv3d_f16s_deconv.hip", []),
+    ("conv3d_f16s_direct.hip", []),
+    ("conv3d_f16s_wd.hip", []),
     ("tail.hip", []),
     ("metrics.hip", []),
     ("volume.hip", ["-ffp-contract=off"]),
@@ -50,8 +58,8 @@ def build(force=False, verbose=True, defines=(), lib=None):
     objdir = os.path.join(HERE, "build" + tag)
     out = lib or LIB                                   # (a variant's path must not stick to later default builds)
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "conv_common.h"), os.path.join(HERE, "..", "include", "msnet_hip.h"),
-               os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, h) for h in ("common.h", "conv_common.h", "conv_f16s.h", "conv_f16s_ws.h")] + [
+        os.path.join(HERE, "..", "include", "msnet_hip.h"), os.path.abspath(__file__)]
     objs = []
     procs = []
     for src, extra in SOURCES:

@@ -14,9 +14,6 @@ static inline int num_cus() {
     if (!cache[dev]) {
         int v = 0;
         cache[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
-#ifdef EXP_STAMP
-        if (const char* e = getenv("MSNET_EXP_BLOCKS")) cache[dev] = atoi(e);   // diagnostic: run the persistent kernels on fewer CUs
-#endif
     }
     return cache[dev];
 }
@@ -32,7 +29,6 @@ struct ConvArgs {
     int nbtot;             // Co / 32
     int nseg, seglen;      // sliding-window kernels: depth segments per tile column, tiles (depth steps) per segment
     unsigned* oflag;       // device word that receives 1 when an output leaves the fp16 range (msnet_set_overflow_flag), or null
-    int stagger;           // -DEXP_STAGGER builds only: start delay per workgroup phase (blockIdx & 3) in units of 1024 cycles
 };
 
 // Range guard of the split-fp16 kernels (conv3d_f16s.hip: every operand's `hi` half is an fp16).  The limit is HALF the largest
@@ -178,40 +174,6 @@ __device__ __forceinline__ void epilogue_store(const f32x16& acc, const f32x16& 
         if (relu) v = fmaxf(v, 0.f);
         amax = fmaxf(amax, ok ? fabsf(v) : 0.f);
         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), y, o, 0, 0);
-    }
-    flag_overflow(oflag, amax);
-}
-
-// Split-record output ("SR"): a voxel's 32-channel group is stored as [hi c0..c31 (64 B) | lo c0..c31 (64 B)] fp16 -- the
-// split the consumer's loader would otherwise compute (hi = fp16(v), lo = fp16((v - hi) * 2^11)), in the same 128 bytes the
-// fp32 values take.  A lane holds channel r = lane & 31 of a voxel: it computes its own hi / lo, swaps one of them with its
-// neighbour lane (r ^ 1, one DPP move) and stores one dword -- even lanes {hi[r], hi[r+1]} at byte r*2 of the hi half, odd
-// lanes {lo[r-1], lo[r]} at byte (r-1)*2 of the lo half.  `off` is the lane's byte offset in SR layout (sr_lane_offset).
-__device__ __forceinline__ unsigned sr_lane_offset(unsigned off_f32, int r) {      // fp32-layout offset of channel r -> SR dword slot
-    return off_f32 - (unsigned)(r * 4) + (unsigned)((r & 1) * 64 + (r >> 1) * 4);
-}
-
-template <int BW, class Valid>
-__device__ __forceinline__ void epilogue_store_split(const f32x16& acc, const f32x16& rv, float sc, float sh,
-                                                     __amdgpu_buffer_rsrc_t y, unsigned off, int stride_h, int stride_w, int relu,
-                                                     Valid valid, int r, unsigned* oflag = nullptr) {
-    float amax = 0.f;
-    const bool odd = r & 1;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int c = (e & 3) + 8 * (e >> 2);
-        const bool ok = valid(c / BW, c % BW);
-        const unsigned o = ok ? off + (unsigned)((c / BW) * stride_h + (c % BW) * stride_w) : 0xffffffffu;
-        float v = acc[e] * sc + sh + rv[e];
-        if (relu) v = fmaxf(v, 0.f);
-        amax = fmaxf(amax, ok ? fabsf(v) : 0.f);
-        const _Float16 h = (_Float16)v;
-        const _Float16 l = (_Float16)((v - (float)h) * 2048.f);
-        const unsigned hb = __builtin_bit_cast(unsigned short, h), lb = __builtin_bit_cast(unsigned short, l);
-        const unsigned send = odd ? hb : lb;
-        const unsigned recv = (unsigned)__builtin_amdgcn_mov_dpp((int)send, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]: lane r ^ 1
-        const unsigned word = odd ? (recv | (lb << 16)) : (hb | (recv << 16));
-        __builtin_amdgcn_raw_buffer_store_b32(word, y, o, 0, 0);
     }
     flag_overflow(oflag, amax);
 }

@@ -150,6 +150,19 @@ extern "C" double msnet_peak_mfma_f16_rand(void* scratch, int iters, int shape16
     return (double)blocks * 4.0 * iters * 8.0 * 2.0 * 32 * 32 * 16;       // both shapes: 8 x 32x32x16 = 16 x 16x16x32 FLOPs per iteration
 }
 
+// One thread stores {shader-clock counter (s_memtime: ticks at the clock the power manager currently grants), constant
+// 100 MHz counter (s_memrealtime)}.  Two probes on one stream bracket a region: granted clock = d(ticks) / d(real time).
+__global__ void clock_probe_kernel(unsigned long long* out) {
+    out[0] = __builtin_readcyclecounter();
+    out[1] = __builtin_amdgcn_s_memrealtime();
+}
+
+extern "C" int msnet_clock_probe(void* device_u64x2, msnet_stream_t stream) {
+    if (!device_u64x2) return msnet::fail("msnet_clock_probe: null pointer");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)device_u64x2);
+    return msnet::check_launch("msnet_clock_probe");
+}
+
 extern "C" int msnet_peak_copy(const void* src, void* dst, size_t bytes, msnet_stream_t stream) {
     if (!src || !dst || bytes < 16) return fail("msnet_peak_copy: bad arguments");
     hipLaunchKernelGGL(peak_copy_kernel, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const f32x4*)src, (f32x4*)dst, bytes / 16);
