@@ -38,8 +38,8 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)", 
 FP16_MATRIX_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md "HBM3E peak BW" (spec); 6290 measured there with a float4 copy
 SPLIT_MFMAS_PER_PRODUCT = 3         # split-fp16: ah*wh, al*wh, ah*wl  
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
-FACTS_FILE = os.path.join(ROOT, "profiles", "r03_profile_facts.json")     # tools/tools_profile_facts.py (rocprofv3 summaries)
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+FACTS_FILE = os.path.join(ROOT, "profiles", "r04_profile_facts.json")     # tools/tools_profile_facts.py (rocprofv3 summaries)
 WORKLOADS = {
     # name: (padded H, W, maxdisp, description)
     "cfg2": (544, 960, 192, "MS-GCNet forward (MS volume build + 19-conv aggregator + soft-argmin), Scene-Flow "
@@ -119,7 +119,8 @@ class PowerMeter:
         e1, t1 = self._energy_j(), time.perf_counter()
         c = [int(v) for v in self.clk.cpu()]
         ticks, real = c[2] - c[0], (c[3] - c[1]) / 1e8
-        return {"power_w": (e1 - self.e0) / (t1 - self.t0) if self.e0 is not None and e1 is not None and t1 > self.t0 else None,
+        # (a region shorter than the counter's update period reads the same count twice: no power figure then)
+        return {"power_w": (e1 - self.e0) / (t1 - self.t0) if self.e0 is not None and e1 is not None and e1 > self.e0 and t1 > self.t0 else None,
                 "energy_j_per_map": None,
                 "sclk_mhz": ticks / real / 1e6 if real > 0 and ticks > 0 else None,
                 "source": "power: package energy counter (rocm_smi_lib) over the timed region; clock: s_memtime / s_memrealtime "
@@ -151,7 +152,7 @@ def pmc_traffic(key, workload, batch):
 
 
 def profile_facts(workload, batch):
-    """Numbers of the committed rocprofv3 passes (profiles/r03_profile_facts.json: average kernel durations of the
+    """Numbers of the committed rocprofv3 passes (profiles/r04_profile_facts.json: average kernel durations of the
     --kernel-trace --stats run and the clock the chip held under the dominant kernel from the SQ/GRBM counter pass), returned
     only when they were taken on this workload, this batch size and THIS kernel source -- so the live line and the tracked
     profile cannot drift apart unnoticed.  Otherwise None."""
@@ -570,10 +571,11 @@ def main():
         facts = profile_facts(args.workload, B)
         if facts:
             # the tracked rocprofv3 --kernel-trace --stats run of this very source: average duration of the dominant family's launches
-            ns = facts.get("kernel_avg_ns", {}).get(dom_family)
-            if ns and dom["calls"]:
-                fl = dom["flops"] / dom["calls"]
-                line["roofline"]["avg_launch_ms_rocprof"] = ns * 1e-6
+            ns = facts.get("family_ns_per_step", {}).get(dom_family)          # all launches of the family in one step (= one map)
+            nl = facts.get("family_launches_per_step", {}).get(dom_family)
+            if ns and nl and dom["calls"]:
+                fl = dom["flops"] / dom_steps / B                            # the family's algorithmic FLOPs per map
+                line["roofline"]["avg_launch_ms_rocprof"] = ns * 1e-6 / nl
                 line["roofline"]["frac_rocprof"] = fl / (ns * 1e-9) / 1e12 / peak
             else:
                 line["roofline"].update(avg_launch_ms_rocprof=None, frac_rocprof=None)

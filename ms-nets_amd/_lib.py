@@ -87,8 +87,16 @@ def load():
             "libmsnet_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
             "there is no CPU fallback for this path." % LIB_PATH)
     lib = ctypes.CDLL(LIB_PATH)
+    variant = bool(os.environ.get("MSNET_HIP_LIB"))
     for name, (res, args) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError => ABI mismatch, fail loudly
+        try:
+            fn = getattr(lib, name)      # AttributeError => ABI mismatch, fail loudly
+        except AttributeError:
+            # only an A/B library named through MSNET_HIP_LIB (an older build of the same ABI) may lack a newer entry point:
+            # calling it raises; the shipped library must export every symbol (tests/test_abi.py)
+            if not variant:
+                raise
+            continue
         fn.restype = res
         fn.argtypes = args
     if lib.msnet_version() != 1:

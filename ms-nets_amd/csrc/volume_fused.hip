@@ -818,10 +818,18 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
         };
         int rc = 0;
         const bool wide = (size_t)(27 + kSW) * LS * sizeof(float) > 160 * 1024;     // full-resolution KITTI widths: 16-row bands
+        // the channels-last build runs these kernels ALONE (nothing to overlap them with): 35-row bands -- 8 x 96 = 768 workgroups
+        // at config #2 instead of 1056, three full rounds of one per CU -- measured 45 vs 55 us (profiles/r04_band_cfg.txt)
+        const bool tall = channels_last && band_cfg == 0 && (size_t)(35 + kSW) * LS * sizeof(float) <= 160 * 1024 &&
+                          a.bh - kSW / 2 - 1 <= 35;
         if (wide) rc = launch(std::integral_constant<int, 11>{}, std::integral_constant<int, 256>{});
+        else if (tall) rc = launch(std::integral_constant<int, 35>{}, std::integral_constant<int, 512>{});
         else if (band_cfg == 1) rc = launch(std::integral_constant<int, 27>{}, std::integral_constant<int, 256>{});
         else if (band_cfg == 2) rc = launch(std::integral_constant<int, 11>{}, std::integral_constant<int, 256>{});
         else if (band_cfg == 3) rc = launch(std::integral_constant<int, 59>{}, std::integral_constant<int, 512>{});
+        else if (band_cfg == 4) rc = launch(std::integral_constant<int, 19>{}, std::integral_constant<int, 512>{});
+        else if (band_cfg == 5) rc = launch(std::integral_constant<int, 19>{}, std::integral_constant<int, 256>{});
+        else if (band_cfg == 6) rc = launch(std::integral_constant<int, 35>{}, std::integral_constant<int, 512>{});
         else rc = launch(std::integral_constant<int, 27>{}, std::integral_constant<int, 512>{});
         if (rc) return rc;
     }

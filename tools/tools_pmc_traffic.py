@@ -1,4 +1,4 @@
-"""Aggregates the FETCH_SIZE / WRITE_SIZE passes of tools_pmc_traffic.sh into profiles/r03_pmc_traffic.json (stdout) and a
+"""Aggregates the FETCH_SIZE / WRITE_SIZE passes of tools_pmc_traffic.sh into profiles/r04_pmc_traffic.json (stdout) and a
 per-kernel table (stderr).  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts wide coalesced reads at half
 their bytes (MI355X_MICROARCH.md, HBM) and is doubled here, WRITE_SIZE is exact for 16-byte-per-lane stores."""
 import collections, csv, glob, hashlib, json, os, sys
@@ -40,26 +40,38 @@ def pick(pred):
 
 
 out = {}
-dom = pick(lambda k: "conv3d_wd_f16s_kernel" in k)          # conv3dbn_2: the Winograd-depth kernel ...
-if not dom:
-    dom = pick(lambda k: "conv3d_k3s1_f16s_ws" in k and "true, 4>" in k.replace("(bool)1", "true"))      # ... or the sliding-window direct kernel
+CONV_SRC = sorted(f for f in os.listdir(os.path.join(repo, "ms-nets_amd", "csrc")) if f.startswith(("conv3d_f16s", "conv_f16s", "conv_common")))
+dom = pick(lambda k: "conv3d_wd_f16s_kernel" in k)          # conv3dbn_2: the Winograd-depth kernel
 if dom:
     k, n, fb, wb = dom[0]
-    mf = sq["SQ_VALU_MFMA_BUSY_CYCLES"].get(k); bz = sq["SQ_BUSY_CYCLES"].get(k); gr = sq["GRBM_GUI_ACTIVE"].get(k)
-    out["conv3d_s1_wd_f16s" if "conv3d_wd_f16s_kernel" in k else "conv3d_s1_f16s_co32"] = {
-        "workload": "cfg2", "batch_per_gpu": 1, "sources": ["conv3d_f16s.hip", "conv_common.h"], "source_sha16": sha(["conv3d_f16s.hip", "conv_common.h"]),
+    out["conv3d_s1_wd_f16s"] = {
+        "workload": "cfg2", "batch_per_gpu": 1, "sources": CONV_SRC, "source_sha16": sha(CONV_SRC),
         "kernel": k, "hbm_bytes": fb + wb, "fetch_bytes_x2": fb, "write_bytes": wb,
         "algorithmic_bytes": 2.0 * 96 * 272 * 480 * 32 * 4,
         "note": "conv3dbn_2 per launch; FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE exact",
     }
-vol = pick(lambda k: any(s in k for s in ("vprep_kernel", "features4_kernel", "sadsob_bandsum_kernel", "sadsob_band_kernel")))
+# the Co = 64 stride-1 family (bench.py's dominant family by total time): bytes per MAP summed over its eight launches
+co64 = pick(lambda k: "conv3d_k3s1_f16s_ws<2, 8, 16, 16, 2, 2" in k or "conv3d_k3s1_f16s_ws<2, 4, 32, 32, 2, 2, true" in k or
+            "conv3d_direct_f16s_kernel<false, 8>" in k)
+if co64 and dom:
+    maps = dom[0][1]
+    fb = sum(r[2] * r[1] for r in co64) / maps; wb = sum(r[3] * r[1] for r in co64) / maps
+    v = [48 * 136 * 240] * 2 + [24 * 68 * 120] * 2 + [12 * 34 * 60] * 2           # 64 -> 64 outputs (+ 2 x 128 -> 128 at 6 x 17 x 30)
+    out["conv3d_s1_f16s_co64"] = {
+        "workload": "cfg2", "batch_per_gpu": 1, "sources": CONV_SRC, "source_sha16": sha(CONV_SRC),
+        "kernels": [r[0] for r in co64], "launches_per_map": sum(r[1] for r in co64) / maps,
+        "hbm_bytes": fb + wb, "fetch_bytes_x2": fb, "write_bytes": wb,
+        "algorithmic_bytes": sum(2.0 * x * 64 * 4 for x in v) + 2 * 2.0 * 6 * 17 * 30 * 128 * 4,
+        "note": "per map, summed over the family's launches; FETCH_SIZE doubled (gfx950 wide-read correction), WRITE_SIZE exact",
+    }
+vol = pick(lambda k: any(s in k for s in ("vprep_kernel", "features4_kernel", "features_cl_kernel", "sadsob_bandsum_kernel", "sadsob_band_kernel")))
 if vol:
     # per MAP: a kernel may be launched more than once per build (features4_kernel: matchers 0-2, then Sobel-SAD), so every
     # kernel's bytes are summed over all its calls and divided by the number of builds (= calls of vprep_kernel)
     maps = max(r[1] for r in vol if "vprep_kernel" in r[0])
     per_map = {r[0]: (r[2] * r[1] / maps, r[3] * r[1] / maps, r[1] / maps) for r in vol}
     fb = sum(v[0] for v in per_map.values()); wb = sum(v[1] for v in per_map.values())
-    src = ["volume_fused.hip", "volume.hip"]
+    src = ["volume_fused.hip", "volume.hip"]          # (+ common.h: unchanged across rounds)
     out["volume_build"] = {
         "workload": "cfg2", "batch_per_gpu": 1, "sources": src, "source_sha16": sha(src),
         "kernels": {k: {"launches_per_map": v[2], "fetch_bytes_x2": v[0], "write_bytes": v[1]} for k, v in per_map.items()},

@@ -1,6 +1,6 @@
 """Times the fused matching-space volume build at a benchmark shape (HIP events via the library's own per-launch
 profiler) and prints the per-kernel split.  Also the workload of the volume PMC passes (tools_pmc_volume.sh).
-   python tools_volume_bench.py [cfg2|cfg5|cfg1] [reps]"""
+   python tools_volume_bench.py [cfg2|cfg5|cfg1] [reps] [ndhwc]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,8 +16,9 @@ if __name__ == "__main__":
     dev = torch.device("cuda")
     l, r, _ = synthetic.stereo_pair(hh, wh, nd, seed=0)
     l, r = torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev)
-    vb = cbmv_generator.VolumeBuilder(hh + 20, wh + 20, nd, dev)
-    out = torch.empty((8, nd, hh, wh), device=dev)
+    layout = "ndhwc" if "ndhwc" in sys.argv[1:] else "ncdhw"
+    vb = cbmv_generator.VolumeBuilder(hh + 20, wh + 20, nd, dev, layout=layout)
+    out = torch.empty(vb.out_shape, device=dev)
     for _ in range(3):
         vb(l, r, out=out)
     torch.cuda.synchronize()
@@ -28,7 +29,7 @@ if __name__ == "__main__":
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     alg = 4.0 * 8 * nd * hh * wh + 2.0 * (hh + 20) * (wh + 20)
-    print("%s volume build: %.3f ms per map back to back = %.0f GB/s algorithmic (%.1f MB)" % (name, ms, alg / ms / 1e6, alg / 1e6))
+    print("%s [%s] volume build: %.3f ms per map back to back = %.0f GB/s algorithmic (%.1f MB)" % (name, layout, ms, alg / ms / 1e6, alg / 1e6))
     _lib.prof_enable(True)
     for _ in range(reps):
         vb(l, r, out=out)
