@@ -109,6 +109,17 @@ class ModuleState:
         with self._mu:
             self._slots.clear()
 
+    # copy.deepcopy(model) / pickling a whole module (torch.save(model)): device state is not part of a model's value -- a copy
+    # starts with empty slots of its own (locks, arenas and packed weights are neither copyable nor meaningful elsewhere)
+    def __deepcopy__(self, memo):
+        return ModuleState()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, state):
+        self.__init__()
+
 
 def _slot_property(name):
     def get(self):

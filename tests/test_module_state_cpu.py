@@ -68,3 +68,21 @@ def test_graph_cache_drops_stale_parameter_states_and_is_bounded_in_bytes():
               ("in", 3, "split-fp16", "new"): {"graph": object(), "arena": FakeArena(20 << 30)}}
     hipops._evict_graphs(graphs, "new")
     assert list(graphs) == [("in", 3, "split-fp16", "new")]           # the stale state first, then oldest until under the byte bound
+
+
+def test_module_survives_deepcopy_and_pickle():
+    """copy.deepcopy(model) and torch.save(model) (whole-module pickling) are common in training scripts: the device state holds
+    locks and device buffers, so a copy gets fresh, empty state of its own instead of failing on the lock."""
+    import copy
+    import io
+    m = GCNet_CostVolumeAggre(32).eval()
+    m._forced_precision = "fp32"
+    c = copy.deepcopy(m)
+    assert c.__dict__["_state"] is not m.__dict__["_state"] and c._forced_precision is None and c._graphs == {}
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), c.state_dict().values()))
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    r = torch.load(buf, weights_only=False)
+    assert r._forced_precision is None and isinstance(r.__dict__["_state"], hipops.ModuleState)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), r.state_dict().values()))
