@@ -331,6 +331,8 @@ def main():
                     help="torch.distributed backend (default: RCCL = 'nccl'; env MSNET_DIST_BACKEND).  'gloo' lets several ranks share "
                          "one GPU (LOCAL_RANK modulo the device count, collective through host memory): a functional run of the "
                          "world > 1 path on a 1-GPU box, not a measurement")
+    ap.add_argument("--wd64", action="store_true",
+                    help="experiment (DESIGN 10): the 64->64 stride-1 layers as four Winograd-depth launches each -- diagnostic")
     ap.add_argument("--self-launch", action="store_true",
                     help="start the ranks as a child `python -m torch.distributed.run` even for --gpus 1 (what --gpus N>1 does by "
                          "itself when no launcher set RANK)")
@@ -358,6 +360,8 @@ def main():
     torch.cuda.set_device(dev)
     _lib.load()
     hipops.set_default_precision(args.precision)
+    if args.wd64:
+        hipops.USE_WD64 = True
 
     H, W, D, desc = WORKLOADS[args.workload]
     hh, wh, nd = H // 2, W // 2, D // 2

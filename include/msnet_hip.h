@@ -196,6 +196,13 @@ int msnet_conv3d_k3_wd_f16s_supported(int D, int H, int W, int Ci, int Co, int s
 int msnet_conv3d_k3_wd_f16s(const float* x, const void* wpk_wd, const float* scale, const float* shift,
                             const float* residual, float* y, int N, int D, int H, int W, int relu,
                             msnet_stream_t stream);
+/* Experiment entry: the same kernel on 32-channel slices of wider channels-last tensors -- x / y /
+ * residual point at the slice's first channel inside records of x_channels / y_channels floats.  With it a
+ * 64 -> 64 layer (gcnet_3dcnn.py:30-44, convs 2 and 3 of a Conv3DBlock) runs as four Winograd-depth launches, the partial sum of
+ * the first input half handed to the second through `residual`.  Measured slower than the direct kernel; not on the default path. */
+int msnet_conv3d_k3_wd_f16s_strided(const float* x, const void* wpk_wd, const float* scale, const float* shift,
+                                    const float* residual, float* y, int N, int D, int H, int W, int x_channels,
+                                    int y_channels, int relu, msnet_stream_t stream);
 /* The first layer (cbmv_in_planes = 8, gcnet_3dcnn.py:99-101) read straight from the module's NCDHW volume
  * x: f32[N][8][D][H][W] (the layout cbmv_generator.py:307-308 produces) -> y: NDHWC f32[N][D][H][W][Co], Co = 32 or 64, stride 1,
  * no residual; split-fp16 MFMA.  Replaces msnet_ncdhw_to_ndhwc + msnet_conv3d_k3_f16s for that layer: the volume is not

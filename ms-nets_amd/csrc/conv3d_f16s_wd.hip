@@ -70,11 +70,11 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
         for (int u = 0; u < PL; ++u) {
             const int sl = u * LT + lt, pos = sl >> 3, c4 = sl & 7;
             const int ih = pos / IW, iw = pos % IW;
-            goff_[u] = (unsigned)(((ih * a.W + iw) * 32 + c4 * 4) * 4);
+            goff_[u] = (unsigned)(((ih * a.W + iw) * a.Ci + c4 * 4) * 4);      // a.Ci: channels per input voxel RECORD (32, or 64 for a half of a 64-channel tensor)
             loff_[u] = (ih * 4 * IW + iw) * RB + (c4 & 1) * 8 + (((c4 >> 1) ^ ((iw >> 1) & 7)) << 4);   // (+ k * IW * RB: plane k)
             mask0 |= (sl < PSLOT ? 1u : 0u) << u;
         }
-        const size_t sample_bytes = (size_t)a.D * a.H * a.W * 32 * 4;
+        const size_t sample_bytes = (size_t)a.D * a.H * a.W * a.Ci * 4;
         // Raw planes of the tile whose q planes are being built: p0, p1 in one register set, p2, p3 in the other.  Inside a column
         // the next tile's p0, p1 ARE this tile's p2, p3, so the two sets swap roles from tile to tile (the tile body exists once per
         // parity: no register copies) and only two planes are fetched per tile.
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
             const int gd = c.od0 - 1 + pl, ih0 = c.oh0 - 1, iw0 = c.ow0 - 1;
             const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (size_t)c.n * (sample_bytes / 4), 0,
                                                                 (int)sample_bytes, 0x00020000);
-            const unsigned base = (unsigned)((((long)gd * a.H + ih0) * a.W + iw0) * 32) * 4u;
+            const unsigned base = (unsigned)((((long)gd * a.H + ih0) * a.W + iw0) * a.Ci) * 4u;
             const bool interior = ih0 >= 0 && ih0 + IH <= a.H && iw0 >= 0 && iw0 + IW <= a.W;
             unsigned mask = mask0;
             if (!interior) {
@@ -383,7 +383,8 @@ static int launch_wd_f16s(const char* name, ConvArgs a, hipStream_t s) {
     const size_t units = cols * a.nseg;
     const size_t nblk = units < (size_t)num_cus() ? units : (size_t)num_cus();
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
-    LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox, 4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
+    // (a.Ci / a.Co are record strides here; the kernel always contracts 32 x 32 channels)
+    LaunchScope ls(name, s, 2.0 * 27.0 * 32 * 32 * vox, 4.0 * ((double)a.N * a.D * a.H * a.W * 32 + vox * 32 * (a.res ? 2 : 1)));
     hipLaunchKernelGGL(conv3d_wd_f16s_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
     return check_launch(name);
 }
@@ -424,5 +425,25 @@ extern "C" int msnet_conv3d_k3_wd_f16s(const float* x, const void* wpk_wd, const
     a.OD = D; a.OH = H; a.OW = W;
     const int rc = launch_wd_f16s("conv3d_s1_wd_f16s", a, (hipStream_t)stream);
     if (rc < 0) return fail("msnet_conv3d_k3_wd_f16s: a sample exceeds the kernel's 32-bit offset range");
+    return rc;
+}
+
+// The same kernel on 32-channel SLICES of wider channels-last tensors: x points at the first of its 32 input channels inside
+// records of x_channels floats, y (and residual) at the first of its 32 output channels inside records of y_channels floats.
+// Experiment entry (a 64 -> 64 layer as four Winograd-depth launches, partial sums handed over through `residual`).
+extern "C" int msnet_conv3d_k3_wd_f16s_strided(const float* x, const void* wpk_wd, const float* scale, const float* shift,
+                                               const float* residual, float* y, int N, int D, int H, int W, int x_channels,
+                                               int y_channels, int relu, msnet_stream_t stream) {
+    if (!x || !wpk_wd || !y) return fail("msnet_conv3d_k3_wd_f16s_strided: null pointer");
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_conv3d_k3_wd_f16s_strided: empty input");
+    if (x_channels < 32 || x_channels % 32 || y_channels < 32 || y_channels % 32)
+        return fail("msnet_conv3d_k3_wd_f16s_strided: record widths %d / %d (multiples of 32)", x_channels, y_channels);
+    ConvArgs a{};
+    a.x = x; a.wpk = reinterpret_cast<const f32x4*>(wpk_wd); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = x_channels; a.Co = y_channels; a.relu = relu; a.oflag = overflow_flag();
+    a.OD = D; a.OH = H; a.OW = W;
+    // (the descriptors span D*H*W records from the slice's first channel: the last record's tail beyond the slice is never touched)
+    const int rc = launch_wd_f16s("conv3d_s1_wd_f16s", a, (hipStream_t)stream);
+    if (rc < 0) return fail("msnet_conv3d_k3_wd_f16s_strided: a sample exceeds the kernel's 32-bit offset range");
     return rc;
 }

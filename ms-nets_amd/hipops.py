@@ -225,6 +225,10 @@ def get_default_precision():
 
 
 USE_WINOGRAD_DEPTH = True      # 32 -> 32 stride-1 layers on the Winograd-depth kernel where the shape is taken (A/B switch)
+# Experiment: 64 -> 64 stride-1 layers as FOUR Winograd-depth launches on 32-channel slices
+# (two output halves x two input halves, the first input half's partial sum handed over as the second launch's residual).
+# Measured slower than the direct kernel at 48x136x240 -- off; bench.py --wd64 / tools_layer_bench.py switch it on.
+USE_WD64 = os.environ.get("MSNET_WD64", "0") == "1"
 
 
 def winograd_depth_weights(w):
@@ -257,9 +261,35 @@ def conv3d_k3_winograd_depth(x, wpk_wd, scale, shift, relu=False, residual=None)
     return y
 
 
-def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16s=False, wpk_wd=None):
+def conv3d_k3_wd64(x, wpk_wd4, scale, shift, relu=False):
+    """64 -> 64 stride-1 conv as four Winograd-depth launches (USE_WD64).  wpk_wd4[h][c]: packed image of w[32h:32h+32, 32c:32c+32]."""
     x = require_gpu_f32(x, "x")
     n, d, h, w, ci = x.shape
+    y = _new((n, d, h, w, 64), x.device)
+    lib = _lib.load()
+    for hh in range(2):
+        yv, xs = c_void_p_off(y, 32 * hh), None
+        sc = c_void_p_off(scale, 32 * hh) if scale is not None else None
+        sh = c_void_p_off(shift, 32 * hh) if shift is not None else None
+        check(lib.msnet_conv3d_k3_wd_f16s_strided(c_void_p_off(x, 0), ptr(wpk_wd4[hh][0]), sc, None, None, yv, n, d, h, w, 64, 64, 0,
+                                                  stream_ptr()), "msnet_conv3d_k3_wd_f16s_strided")
+        check(lib.msnet_conv3d_k3_wd_f16s_strided(c_void_p_off(x, 32), ptr(wpk_wd4[hh][1]), sc, sh, yv, yv, n, d, h, w, 64, 64,
+                                                  int(relu), stream_ptr()), "msnet_conv3d_k3_wd_f16s_strided")
+    return y
+
+
+def c_void_p_off(t, floats):
+    """Device pointer of tensor t advanced by `floats` fp32 elements."""
+    import ctypes
+    return ctypes.c_void_p(t.data_ptr() + 4 * int(floats))
+
+
+def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16s=False, wpk_wd=None, wpk_wd4=None):
+    x = require_gpu_f32(x, "x")
+    n, d, h, w, ci = x.shape
+    if (wpk_wd4 is not None and f16s and USE_WD64 and residual is None and stride == 1 and ci == 64 and co == 64 and
+            _lib.load().msnet_conv3d_k3_wd_f16s_supported(d, h, w, 32, 32, 1)):
+        return conv3d_k3_wd64(x, wpk_wd4, scale, shift, relu=relu)
     if (wpk_wd is not None and f16s and USE_WINOGRAD_DEPTH and
             _lib.load().msnet_conv3d_k3_wd_f16s_supported(d, h, w, ci, co, stride)):
         return conv3d_k3_winograd_depth(x, wpk_wd, scale, shift, relu=relu, residual=residual)
@@ -675,6 +705,11 @@ class ConvBNPlan:
         self.wpk_wd = None
         if self.f16s and not transposed and stride == 1 and ci == 32 and self.co == 32:
             self.wpk_wd = winograd_depth_weights(w.float())
+        self.wpk_wd4 = None                 # experiment: four 32 x 32 Winograd images of a 64 -> 64 layer (USE_WD64)
+        if USE_WD64 and self.f16s and not transposed and stride == 1 and ci == 64 and self.co == 64:
+            wf_ = w.float()
+            self.wpk_wd4 = [[winograd_depth_weights(wf_[32 * hh:32 * hh + 32, 32 * cc:32 * cc + 32].contiguous()) for cc in range(2)]
+                            for hh in range(2)]
 
 
 def _registered_tensors(module):

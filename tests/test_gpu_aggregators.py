@@ -1139,3 +1139,25 @@ def test_forward_ndhwc_equals_forward(gpu):
         m.forward_ndhwc(big.permute(0, 2, 3, 4, 1).contiguous().cuda())
     with pytest.raises(ValueError):
         m.forward_ndhwc(x.cuda())                           # an NCDHW tensor is not a channels-last volume of 8 planes
+
+
+def test_winograd_depth_on_channel_slices(gpu):
+    """msnet_conv3d_k3_wd_f16s_strided (experiment entry): a 64 -> 64 layer as four Winograd-depth launches on
+    32-channel slices of the 64-channel records, partial sums handed over through the residual -- same 5e-6 bound vs the fp64
+    convolution as every other split-fp16 layer; odd depth, edge tiles, batch 2."""
+    from msnets_amd import hipops
+    g = torch.Generator().manual_seed(17)
+    for (n, d, h, w), relu in (((1, 5, 9, 40), True), ((2, 4, 8, 33), False)):
+        x = torch.randn((n, 64, d, h, w), generator=g)
+        wt = torch.randn((64, 64, 3, 3, 3), generator=g) * 0.05
+        scale = torch.rand(64, generator=g) + 0.5
+        shift = torch.randn(64, generator=g) * 0.1
+        ref = F.conv3d(x.double(), wt.double(), None, padding=1) * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
+        if relu:
+            ref = F.relu(ref)
+        wg = wt.cuda()
+        wd4 = [[hipops.winograd_depth_weights(wg[32 * a:32 * a + 32, 32 * b:32 * b + 32].contiguous()) for b in range(2)] for a in range(2)]
+        y = hipops.conv3d_k3_wd64(_cl(x), wd4, scale.cuda(), shift.cuda(), relu=relu)
+        err = _rel(_nc(y).double(), ref)
+        print("WD64 (four strided Winograd-depth launches) rel err %.2e" % err)
+        assert err < 5e-6

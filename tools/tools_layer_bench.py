@@ -37,7 +37,10 @@ def run(name, prec, reps=5):
         res = torch.rand((1, *od, co), device=dev) if use_res else None
         wd = (hipops.winograd_depth_weights(wt) if f16s and ci == 32 and co == 32 and stride == 1 and
               os.environ.get("MSNET_LB_WD", "1") != "0" else None)         # MSNET_LB_WD=0: the direct split-fp16 kernel
-        fn = lambda: hipops.conv3d_k3(x, wpk, None, None, co, stride=stride, relu=True, residual=res, f16s=f16s, wpk_wd=wd)
+        wd4 = None
+        if hipops.USE_WD64 and f16s and ci == 64 and co == 64 and stride == 1:          # MSNET_WD64=1: four Winograd-depth launches
+            wd4 = [[hipops.winograd_depth_weights(wt[32 * a:32 * a + 32, 32 * b:32 * b + 32].contiguous()) for b in range(2)] for a in range(2)]
+        fn = lambda: hipops.conv3d_k3(x, wpk, None, None, co, stride=stride, relu=True, residual=res, f16s=f16s, wpk_wd=wd, wpk_wd4=wd4)
         vox = od[0] * od[1] * od[2]
     else:
         wt = (torch.randn((ci, co, 3, 3, 3), generator=g) * 0.05).to(dev)
