@@ -444,7 +444,7 @@ __global__ __launch_bounds__(256) void conv_cout1_kernel(const float* __restrict
 // 27 tap partials T[voxel][tap] are computed once, parked in LDS, and each output voxel (h, w) adds, for kd = 0,1,2, the nine
 // partials T[(h+kh-1, w+kw-1)][kd,kh,kw] of its 3x3 neighbourhood; kd = 2 finishes out[P-1], kd = 1 goes to out[P], kd = 0 to
 // out[P+1].  A workgroup multiplies 8 x 32 input voxels per slice (origin h0-1, w0-1) and finishes the inner 6 x 30 outputs.
-__global__ __launch_bounds__(256) void conv_cout1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, float wsc,
+__global__ __launch_bounds__(256, 4) void conv_cout1_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w, float wsc,
                                                               const float* __restrict__ add, float* __restrict__ y, int N,
                                                               int D, int H, int W, int nth, int ntw, int nseg, int dseg) {
     // A workgroup walks the depth slices of ONE SEGMENT [o0, o1) of output slices of its (h, w) tile: the (h, w) tiles alone
@@ -715,12 +715,12 @@ extern "C" int msnet_conv3d_k3_cout1(const float* x, const float* w, float wscal
                            W, nth, ntw);
     } else {
         const int nth = cdiv(H, 6), ntw = cdiv(W, 30);
-        // depth segments: enough workgroups for ~3 per CU (37 KB of LDS each: four fit), segments of at least 6 slices (each
-        // costs two halo slices of extra reads)
+        // depth segments: enough workgroups for four per CU (37 KB of LDS and 116 registers each: four fit), segments of at least
+        // 8 slices (each costs two halo slices of extra reads)
         const long tiles = (long)N * nth * ntw;
-        int nseg = (int)((3L * num_cus_tail() + tiles - 1) / tiles);
+        int nseg = (int)((4L * num_cus_tail() + tiles - 1) / tiles);
         nseg = nseg < 1 ? 1 : nseg;
-        if (nseg > cdiv(D, 6)) nseg = cdiv(D, 6);
+        if (nseg > cdiv(D, 8)) nseg = cdiv(D, 8);
         const int dseg = cdiv(D, nseg);
         nseg = cdiv(D, dseg);
         hipLaunchKernelGGL(conv_cout1_mfma_kernel, dim3((unsigned)(tiles * nseg)), dim3(256), 0, s, x, w, wscale, add, y, N, D, H, W,
