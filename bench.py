@@ -80,8 +80,9 @@ class PowerMeter:
                read right before and right after the region -> joules / seconds.  Reads sysfs through the library: no HIP
                call, no child process.  (The instantaneous hwmon files of this pool -- power1_input, freq1_input, pp_dpm_sclk --
                read IDLE values while the GPU is loaded, profiles/r04_power_probe.txt, so they are not used.)
-    sclk_mhz : two one-thread kernels (msnet_clock_probe) on the step's stream, the first in front of the first step and the
-               second behind the last: shader-clock ticks (s_memtime) / constant-100-MHz ticks (s_memrealtime) between them.
+    sclk_mhz : two probe launches (msnet_clock_probe: one thread per XCD records its XCD's counters) on the step's stream, the
+               first in front of the first step and the second behind the last: shader-clock ticks (s_memtime) / constant-100-MHz
+               ticks (s_memrealtime) between them, per XCD, averaged.
     Every field is None where the box offers no such source."""
 
     def __init__(self, index, dev):
@@ -95,7 +96,7 @@ class PowerMeter:
                     break
             except (OSError, AttributeError):
                 pass
-        self.clk = torch.zeros(4, dtype=torch.int64, device=dev)
+        self.clk = torch.zeros(32, dtype=torch.int64, device=dev)          # two probes x 8 XCDs x {shader ticks, 100 MHz ticks}
 
     def _energy_j(self):
         if self.rsmi is None:
@@ -114,17 +115,22 @@ class PowerMeter:
     def stop(self):
         """Call behind the region's closing synchronize."""
         from msnets_amd import _lib
-        _lib.check(_lib.load().msnet_clock_probe(_lib.ptr(self.clk[2:]), _lib.stream_ptr()), "msnet_clock_probe")
+        _lib.check(_lib.load().msnet_clock_probe(_lib.ptr(self.clk[16:]), _lib.stream_ptr()), "msnet_clock_probe")
         torch.cuda.synchronize()
         e1, t1 = self._energy_j(), time.perf_counter()
         c = [int(v) for v in self.clk.cpu()]
-        ticks, real = c[2] - c[0], (c[3] - c[1]) / 1e8
+        per_xcd = []                        # the XCDs' shader-clock counters are separate counters: one ratio per XCD, then the mean
+        for i in range(8):
+            t0_, r0_, t1_, r1_ = c[2 * i], c[2 * i + 1], c[16 + 2 * i], c[16 + 2 * i + 1]
+            if t0_ and t1_ and r1_ > r0_ and t1_ > t0_:
+                per_xcd.append((t1_ - t0_) / ((r1_ - r0_) / 1e8) / 1e6)
+        ticks, real = (sum(per_xcd) / len(per_xcd), 1e-6) if per_xcd else (0, 0)
         # (a region shorter than the counter's update period reads the same count twice: no power figure then)
         return {"power_w": (e1 - self.e0) / (t1 - self.t0) if self.e0 is not None and e1 is not None and e1 > self.e0 and t1 > self.t0 else None,
                 "energy_j_per_map": None,
-                "sclk_mhz": ticks / real / 1e6 if real > 0 and ticks > 0 else None,
+                "sclk_mhz": ticks if per_xcd else None, "sclk_mhz_per_xcd": [round(v, 1) for v in per_xcd],
                 "source": "power: package energy counter (rocm_smi_lib) over the timed region; clock: s_memtime / s_memrealtime "
-                          "between two one-thread kernels around it"}
+                          "between two probe launches around it, per XCD, averaged"}
 
 
 def _source_sha(*names):

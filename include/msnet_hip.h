@@ -67,10 +67,11 @@ double msnet_peak_mfma_f16_16x16(void* scratch, int iters, msnet_stream_t stream
 /* The same rate on CHANGING operands (eight pseudo-random A and four B fragments cycled in registers): what the chip's power
  * management sustains when every MFMA sees fresh data, as in a real kernel.  shape16: 0 = 32x32x16, 1 = 16x16x32. */
 double msnet_peak_mfma_f16_rand(void* scratch, int iters, int shape16, msnet_stream_t stream);   /* same, v_mfma_f32_16x16x32_f16 */
-/* Measurement aid: a one-thread kernel stores {shader-clock ticks (s_memtime), constant 100 MHz ticks (s_memrealtime)} into
- * device_u64x2.  Two probes on one stream around a region give the clock the power manager GRANTED over it:
+/* Measurement aid: a grid of one-thread workgroups stores, per XCD i, {shader-clock ticks (s_memtime), constant 100 MHz ticks
+ * (s_memrealtime)} into device_u64x16[2i], [2i+1] (zero-initialise it; a slot stays zero if no workgroup landed on that XCD).
+ * Two probes on one stream around a region give the clock the power manager GRANTED each XCD over it:
  * d(ticks) / (d(real) / 1e8) Hz -- bench.py's `power.sclk_mhz` (the sysfs clock files of this pool read idle values under load). */
-int    msnet_clock_probe(void* device_u64x2, msnet_stream_t stream);
+int    msnet_clock_probe(void* device_u64x16, msnet_stream_t stream);
 
 /* ---- matchers: replaces src/cpp/matchers/matchers.cpp:565-580 (libmatchers) ----------------- */
 /* census(left,right,ndisp,wsize) matchers.cpp:232-353.  l,r: u8[H][W]; out: f32[H][W][ndisp];

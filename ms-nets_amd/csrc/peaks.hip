@@ -150,16 +150,19 @@ extern "C" double msnet_peak_mfma_f16_rand(void* scratch, int iters, int shape16
     return (double)blocks * 4.0 * iters * 8.0 * 2.0 * 32 * 32 * 16;       // both shapes: 8 x 32x32x16 = 16 x 16x16x32 FLOPs per iteration
 }
 
-// One thread stores {shader-clock counter (s_memtime: ticks at the clock the power manager currently grants), constant
-// 100 MHz counter (s_memrealtime)}.  Two probes on one stream bracket a region: granted clock = d(ticks) / d(real time).
+// Per XCD: one thread stores {shader-clock counter (s_memtime: ticks at the clock the power manager currently grants that XCD),
+// constant 100 MHz counter (s_memrealtime)} into slot XCC_ID of device_u64x16 (8 XCDs x 2).  The shader-clock counters of the
+// XCDs are not one counter, so a probe is a grid of single-thread workgroups -- round-robin dispatch puts some on every XCD --
+// and each writes its own XCD's slot.  Two probes on one stream bracket a region: granted clock of XCD i = d(ticks_i) / d(real_i).
 __global__ void clock_probe_kernel(unsigned long long* out) {
-    out[0] = __builtin_readcyclecounter();
-    out[1] = __builtin_amdgcn_s_memrealtime();
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;          // hwreg(HW_REG_XCC_ID), bits 3:0
+    out[2 * xcc] = __builtin_readcyclecounter();
+    out[2 * xcc + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
-extern "C" int msnet_clock_probe(void* device_u64x2, msnet_stream_t stream) {
-    if (!device_u64x2) return msnet::fail("msnet_clock_probe: null pointer");
-    hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)device_u64x2);
+extern "C" int msnet_clock_probe(void* device_u64x16, msnet_stream_t stream) {
+    if (!device_u64x16) return msnet::fail("msnet_clock_probe: null pointer");
+    hipLaunchKernelGGL(clock_probe_kernel, dim3(64), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)device_u64x16);
     return msnet::check_launch("msnet_clock_probe");
 }
 

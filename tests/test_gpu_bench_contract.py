@@ -46,7 +46,9 @@ def test_bench_json_contract(gpu):
     assert set(p) >= {"power_w", "sclk_mhz", "energy_j_per_map", "source"}
     if p["power_w"] is not None:                      # package energy counter over the timed region (None: region too short for it)
         assert 300 < p["power_w"] < 1500 and abs(p["energy_j_per_map"] - p["power_w"] * d["ms_per_step"] * 1e-3) < 1e-6 * p["power_w"]
-    assert p["sclk_mhz"] is not None and 900 < p["sclk_mhz"] < 2500      # granted clock: s_memtime / s_memrealtime
+    # granted clock: s_memtime / s_memrealtime per XCD, averaged (this 2-step region is ~15 ms: single XCDs scatter, the mean does not)
+    assert p["sclk_mhz"] is not None and 900 < p["sclk_mhz"] < 2500
+    assert 1 <= len(p["sclk_mhz_per_xcd"]) <= 8 and all(200 < v < 3000 for v in p["sclk_mhz_per_xcd"])
     v = d["roofline_volume"]
     assert v["bound"] in ("hbm", "valu-issue") and v["priced_against"] == "hbm" and v["unit"] == "GB/s"
     assert abs(v["frac"] - v["achieved"] / v["peak"]) < 1e-9 and v["hbm_frac"] == v["frac"]
