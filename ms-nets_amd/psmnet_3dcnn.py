@@ -97,7 +97,7 @@ class PSMNet_CostVolumeAggre(hipops.DeviceStateMixin, nn.Module):
             self._plan[precision] = pl
         return self._plan[precision]
 
-    def _trunk(self, cost, taps, precision):
+    def _trunk(self, cost, taps, precision, channels_last=False):
         pl = self._plans(precision)
         if taps is not None:
             taps.clear()
@@ -128,7 +128,12 @@ class PSMNet_CostVolumeAggre(hipops.DeviceStateMixin, nn.Module):
 
         p0 = pl["dres0.0"]
         from .gcnet_3dcnn import FUSE_INPUT_LAYOUT
-        if FUSE_INPUT_LAYOUT and p0.f16s and cost.shape[1] == 8 and p0.co in (32, 64):      # the MS volume: first layer straight from NCDHW
+        if channels_last:                    # forward_ndhwc: the 8-plane MS volume as VolumeBuilder(layout="ndhwc") writes it
+            if p0.f16s and cost.shape[4] == 8 and p0.co in (32, 64):
+                c0 = conv(hipops.conv3d_c8_in(cost, p0.wpk, p0.scale, p0.shift, p0.co, relu=True), "dres0.2")
+            else:                            # (fp32 precision / other widths: the input range check rides on a copy)
+                c0 = conv(conv(hipops.ncdhw_to_ndhwc(cost.permute(0, 4, 1, 2, 3).contiguous()), "dres0.0"), "dres0.2")
+        elif FUSE_INPUT_LAYOUT and p0.f16s and cost.shape[1] == 8 and p0.co in (32, 64):      # the MS volume: first layer straight from NCDHW
             c0 = conv(hipops.conv3d_c8_ncdhw(cost, p0.wpk, p0.scale, p0.shift, p0.co, relu=True), "dres0.2")
         else:
             c0 = conv(conv(hipops.ncdhw_to_ndhwc(cost), "dres0.0"), "dres0.2")
@@ -166,6 +171,25 @@ class PSMNet_CostVolumeAggre(hipops.DeviceStateMixin, nn.Module):
         # (tapped activations are handed to the caller: fresh tensors instead of the arena's)
         return hipops.guarded_forward(self, run, graph_key=(cost.data_ptr(), tuple(cost.shape), H, W) if taps is None else None,
                                       use_arena_=taps is None)
+
+    def forward_ndhwc(self, cost_cl, out_hw=None):
+        """forward() on a CHANNELS-LAST volume [N, D/4, H/4, W/4, in_planes] -- for PSMNet_CostVolumeAggre(maxdisp, in_planes=8)
+        fed by cbmv_generator.VolumeBuilder(layout="ndhwc") (the MS volume at quarter resolution): no layout pass in front of
+        dres0.  Same bits as forward() on the NCDHW volume of the same values.  Not part of the reference's interface."""
+        if getattr(self, "_is_replica", False):
+            raise RuntimeError(hipops.REPLICA_ERROR)
+        if self.training:
+            raise RuntimeError("PSMNet_CostVolumeAggre (HIP) is forward/inference only: call .eval() first")
+        cost_cl = hipops.require_gpu_f32(cost_cl, "cost_cl")
+        if cost_cl.dim() != 5 or cost_cl.shape[4] != self.in_planes:
+            raise ValueError("cost_cl must be [N,D/4,H/4,W/4,%d] (got %s)" % (self.in_planes, tuple(cost_cl.shape)))
+        H, W = out_hw if out_hw is not None else (4 * cost_cl.shape[2], 4 * cost_cl.shape[3])
+
+        def run(precision):
+            with torch.no_grad():
+                _, _, cost3 = self._trunk(cost_cl, None, precision, channels_last=True)
+                return hipops.trilinear_softargmin(cost3, (self.maxdisp, H, W))
+        return hipops.guarded_forward(self, run, graph_key=(cost_cl.data_ptr(), tuple(cost_cl.shape), H, W, "ndhwc"))
 
     def forward_all_heads(self, cost, out_hw=None):
         """(pred1, pred2, pred3) as the reference's training-mode return (psmnet_3dcnn.py:149-177)."""

@@ -1161,3 +1161,24 @@ def test_winograd_depth_on_channel_slices(gpu):
         err = _rel(_nc(y).double(), ref)
         print("WD64 (four strided Winograd-depth launches) rel err %.2e" % err)
         assert err < 5e-6
+
+
+def test_psmnet_forward_ndhwc_equals_forward(gpu):
+    """PSMNet_CostVolumeAggre(in_planes=8).forward_ndhwc on the channels-last MS volume == forward on the NCDHW volume, bit for bit
+    (end to end from two images through VolumeBuilder(layout="ndhwc") at quarter resolution); the 64-plane module takes the
+    copying route and agrees as well."""
+    from msnets_amd import cbmv_generator as cg, synthetic
+    _, P = _our_classes()
+    left, right, _ = synthetic.stereo_pair(32, 48, 16, seed=9)
+    l, r = torch.from_numpy(left).cuda(), torch.from_numpy(right).cuda()
+    vol = cg.build_ms_volume(l, r, 16)                                    # [8, 16, 32, 48]
+    vcl = cg.build_ms_volume(l, r, 16, layout="ndhwc")                    # [16, 32, 48, 8]
+    torch.manual_seed(31)
+    m = P(64, in_planes=8).eval().cuda()
+    assert torch.equal(m.forward_ndhwc(vcl.unsqueeze(0)), m(vol.unsqueeze(0)))
+    torch.manual_seed(32)
+    m64 = P(32).eval().cuda()
+    x = torch.rand(1, 64, 8, 16, 24).cuda()
+    assert torch.equal(m64.forward_ndhwc(x.permute(0, 2, 3, 4, 1).contiguous()), m64(x))
+    with pytest.raises(ValueError):
+        m.forward_ndhwc(vol.unsqueeze(0))

@@ -32,7 +32,19 @@ for k in range(reps):
             bad += 1
             print("cfg2 repeat %d differs: volume %s, disparity max diff %.3e" % (k, torch.equal(vol, ref_vol), float((out - ref).abs().max())))
 print("cfg2: %d repeats, %d differ" % (reps, bad))
-del g, vol, out, ref, ref_vol, builder
+# the channels-last route (round 4): build [D',H',W',8] + forward_ndhwc must return the NCDHW route's bits, every time
+builder_cl = cbmv_generator.VolumeBuilder(hh + 20, wh + 20, nd, dev, layout="ndhwc")
+ref_cl = ref_vol.permute(1, 2, 3, 0).contiguous()
+bad_cl = 0
+for k in range(reps):
+    vcl = builder_cl(l, r)
+    out = g.forward_ndhwc(vcl.unsqueeze(0))
+    if not torch.equal(vcl, ref_cl) or not torch.equal(out, ref):
+        bad_cl += 1
+        print("cfg2 channels-last repeat %d differs: volume %s, disparity max diff %.3e" % (k, torch.equal(vcl, ref_cl), float((out - ref).abs().max())))
+print("cfg2 channels-last: %d repeats, %d differ" % (reps, bad_cl))
+bad += bad_cl
+del g, vol, out, ref, ref_vol, builder, builder_cl, vcl, ref_cl
 torch.cuda.empty_cache()
 p = PSMNet_CostVolumeAggre(D).eval().to(dev)
 x = torch.rand((1, 64, D // 4, H // 4, W // 4), device=dev)
