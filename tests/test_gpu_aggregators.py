@@ -75,7 +75,9 @@ F16S_CASES = [
 ]
 
 
+# (the last two: output widths 16 mod 32 with rows in fours -> the 2x4x16 tile of round 4; 8 x 16 x 96 also has depth / row edge tiles)
 F16S_S2_CASES = [(32, 64, (1, 8, 12, 34), True, False), (64, 64, (1, 6, 9, 33), True, True), (64, 128, (1, 4, 6, 10), True, False),
+                 (32, 64, (1, 7, 16, 96), True, False), (64, 64, (2, 4, 8, 32), True, True),
                  (32, 64, (2, 5, 7, 70), False, False)]
 
 

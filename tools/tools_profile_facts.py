@@ -26,7 +26,8 @@ FAMILIES = {
     "conv3d_s1_wd_f16s": lambda n: "conv3d_wd_f16s_kernel" in n,
     "conv3d_s1_f16s_co64": lambda n: ("conv3d_k3s1_f16s_ws<2, 8, 16, 16, 2, 2" in n or "conv3d_k3s1_f16s_ws<2, 4, 32, 32, 2, 2, true" in n
                                       or "conv3d_direct_f16s_kernel<false, 8>" in n),
-    "conv3d_s2_f16s": lambda n: "conv3d_k3s1_f16s_ws<2, 2, 32, 32, 1, 2" in n or "conv3d_direct_f16s_kernel<false, 4>" in n,
+    "conv3d_s2_f16s": lambda n: ("conv3d_k3s1_f16s_ws<2, 2, 32, 32, 1, 2" in n or "conv3d_k3s1_f16s_ws<2, 4, 16, 16, 1, 2" in n
+                                 or "conv3d_direct_f16s_kernel<false, 4>" in n),
     "deconv3d_f16s": lambda n: "deconv3d_k3s2_f16s_ws" in n or "conv3d_direct_f16s_kernel<true" in n,
     "conv3d_s1_c8_f16s": lambda n: "conv3d_c8_f16s_kernel" in n,
     "deconv5_softargmin": lambda n: "deconv5_tail_mfma_kernel" in n,
