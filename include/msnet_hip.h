@@ -215,16 +215,6 @@ int msnet_conv3d_k3_c8_ncdhw_f16s(const float* x_ncdhw, const void* wpk_f16s, co
  * overflow word), which the layout-conversion pass carries on the NCDHW route.  Entry of GCNet_CostVolumeAggre.forward_ndhwc. */
 int msnet_conv3d_k3_c8_in_f16s(const float* x_ndhwc, const void* wpk_f16s, const float* scale, const float* shift,
                                float* y, int N, int D, int H, int W, int Co, int relu, msnet_stream_t stream);
-/* Stride-2 convbn_3d heads of the encoder levels (gcnet_3dcnn.py:108-114 `Conv3DBlock` conv 1; psmnet_3dcnn.py:69-75 hourglass
- * conv1 / conv3) with Ci = 32 / 64 -> Co = 64 on the 8-channel-chunk kernel (two taps per K-step, 2x4x32 output tile, two M-blocks
- * per wave; csrc/conv3d_f16s_s2c8.hip).  Same arguments and epilogue as msnet_conv3d_k3_f16s with stride 2; its own packed weight
- * image (msnet_pack_conv_weight_s2c8_f16s: (Ci / 8) * 57,344 bytes).  _supported() says whether a shape is taken (small layers
- * stay on the direct kernel). */
-int msnet_conv3d_k3s2_c8_f16s_supported(int D, int H, int W, int Ci, int Co);
-int msnet_pack_conv_weight_s2c8_f16s(const float* w, void* packed, int Ci, int Co, msnet_stream_t stream);
-int msnet_conv3d_k3s2_c8_f16s(const float* x, const void* wpk_s2c8, const float* scale, const float* shift,
-                              const float* residual, float* y, int N, int D, int H, int W, int Ci, int Co, int relu,
-                              msnet_stream_t stream);
 /* Conv3d(Ci->1, k3, p1, bias=False) head (psmnet_3dcnn.py:112-122 classif*.2), optional "+ add"
  * (cost2 = classif2(out2) + cost1, :146-147).  x: NDHWC; w: f32[1][Ci][3][3][3]; y/add: f32[N][D][H][W].
  * y = wscale * conv(x, w) (+ add): the caller may hand over the weights multiplied by a power of two (so that their fp16

@@ -20,7 +20,6 @@ SOURCES = [
     ("conv3d.hip", []),
     ("conv3d_f16s.hip", []),
     ("conv3d_f16s_ws_s2.hip", []),
-    ("conv3d_f16s_s2c8.hip", []),
     ("conv3d_f16s_ws_c16.hip", []),
     ("conv3d_f16s_ws_co64.hip", []),
     ("conv3d_f16s_ws_co32.hip", []),

@@ -151,7 +151,7 @@ class GCNet_CostVolumeAggre(hipops.DeviceStateMixin, nn.Module):
         def conv(x, name, stride=1, residual=None):
             p = pl[name]
             return hipops.conv3d_k3(x, p.wpk, p.scale, p.shift, p.co, stride=stride, relu=True, residual=residual,
-                                     f16s=p.f16s, wpk_wd=p.wpk_wd, wpk_wd4=p.wpk_wd4, wpk_s2c8=p.wpk_s2c8)
+                                     f16s=p.f16s, wpk_wd=p.wpk_wd, wpk_wd4=p.wpk_wd4)
 
         def block(x, name, stride):
             x = conv(x, name + ".convbn_3d_1", stride)

@@ -229,8 +229,6 @@ USE_WINOGRAD_DEPTH = True      # 32 -> 32 stride-1 layers on the Winograd-depth 
 # (two output halves x two input halves, the first input half's partial sum handed over as the second launch's residual).
 # Measured slower than the direct kernel at 48x136x240 -- off; bench.py --wd64 / tools_layer_bench.py switch it on.
 USE_WD64 = os.environ.get("MSNET_WD64", "0") == "1"
-# Stride-2 layers with Co = 64 on the 8-channel-chunk kernel (csrc/conv3d_f16s_s2c8.hip) where the shape is taken (A/B switch)
-USE_S2C8 = os.environ.get("MSNET_S2C8", "1") == "1"
 
 
 def winograd_depth_weights(w):
@@ -286,28 +284,9 @@ def c_void_p_off(t, floats):
     return ctypes.c_void_p(t.data_ptr() + 4 * int(floats))
 
 
-def pack_conv_weight_s2c8(w):
-    """w f32 [64, Ci, 3, 3, 3] (BN-folded, pre-scaled), Ci = 32 / 64 -> packed image of msnet_conv3d_k3s2_c8_f16s."""
-    w = require_gpu_f32(w, "weight")
-    co, ci = int(w.shape[0]), int(w.shape[1])
-    out = torch.empty((ci // 8) * 57344 // 4, device=w.device, dtype=torch.float32)
-    check(_lib.load().msnet_pack_conv_weight_s2c8_f16s(ptr(w), ptr(out), ci, co, stream_ptr()), "msnet_pack_conv_weight_s2c8_f16s")
-    return out
-
-
-def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16s=False, wpk_wd=None, wpk_wd4=None, wpk_s2c8=None):
+def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16s=False, wpk_wd=None, wpk_wd4=None):
     x = require_gpu_f32(x, "x")
     n, d, h, w, ci = x.shape
-    if (wpk_s2c8 is not None and f16s and USE_S2C8 and stride == 2 and co == 64 and
-            _lib.load().msnet_conv3d_k3s2_c8_f16s_supported(d, h, w, ci, co)):
-        y = _new((n, (d - 1) // 2 + 1, (h - 1) // 2 + 1, (w - 1) // 2 + 1, co), x.device)
-        if residual is not None:
-            residual = require_gpu_f32(residual, "residual")
-            if residual.shape != y.shape:
-                raise ValueError("residual shape %s != output shape %s" % (tuple(residual.shape), tuple(y.shape)))
-        check(_lib.load().msnet_conv3d_k3s2_c8_f16s(ptr(x), ptr(wpk_s2c8), ptr(scale), ptr(shift), ptr(residual), ptr(y), n, d, h, w, ci, co,
-                                                    int(relu), stream_ptr()), "msnet_conv3d_k3s2_c8_f16s")
-        return y
     if (wpk_wd4 is not None and f16s and USE_WD64 and residual is None and stride == 1 and ci == 64 and co == 64 and
             _lib.load().msnet_conv3d_k3_wd_f16s_supported(d, h, w, 32, 32, 1)):
         return conv3d_k3_wd64(x, wpk_wd4, scale, shift, relu=relu)
@@ -726,9 +705,6 @@ class ConvBNPlan:
         self.wpk_wd = None
         if self.f16s and not transposed and stride == 1 and ci == 32 and self.co == 32:
             self.wpk_wd = winograd_depth_weights(w.float())
-        self.wpk_s2c8 = None                # stride-2 Co = 64 layers: image of the 8-channel-chunk kernel
-        if self.f16s and not transposed and stride == 2 and self.co == 64 and ci in (32, 64):
-            self.wpk_s2c8 = pack_conv_weight_s2c8(w.float().contiguous())
         self.wpk_wd4 = None                 # experiment: four 32 x 32 Winograd images of a 64 -> 64 layer (USE_WD64)
         if USE_WD64 and self.f16s and not transposed and stride == 1 and ci == 64 and self.co == 64:
             wf_ = w.float()

@@ -1185,38 +1185,3 @@ def test_psmnet_forward_ndhwc_equals_forward(gpu):
     with pytest.raises(ValueError):
         m.forward_ndhwc(vol.unsqueeze(0))
 
-
-S2C8_CASES = [(32, (1, 8, 12, 34), True, False), (64, (1, 6, 9, 33), True, True), (32, (1, 7, 16, 96), True, False),
-              (64, (2, 4, 8, 32), False, True), (32, (2, 5, 7, 70), False, False), (32, (1, 12, 40, 130), True, True)]
-
-
-@pytest.mark.parametrize("ci,dims,relu,use_res", S2C8_CASES)
-def test_conv3d_stride2_c8_chunk_kernel(gpu, hiplib, ci, dims, relu, use_res, monkeypatch):
-    """msnet_conv3d_k3s2_c8_f16s (round 4: 8-channel chunks, two taps per K-step, 2x4x32 tile) vs the fp64 convolution: the 5e-6
-    bound of every split-fp16 layer; odd sizes (edge tiles in d, h, w; the 65-wide input rows de-interleaved in LDS), batch 2,
-    residual, no-ReLU."""
-    from msnets_amd import hipops
-    monkeypatch.setenv("MSNET_DIRECT", "0")
-    co = 64
-    g = torch.Generator().manual_seed(ci * 11 + dims[3])
-    n, d, h, w = dims
-    x = torch.randn((n, ci, d, h, w), generator=g) * 3
-    wt = torch.randn((co, ci, 3, 3, 3), generator=g) * (2.0 / (27 * ci)) ** 0.5
-    scale = torch.rand(co, generator=g) + 0.5
-    shift = torch.randn(co, generator=g) * 0.1
-    ref = F.conv3d(x.double(), wt.double(), None, stride=2, padding=1) * scale.double().view(1, -1, 1, 1, 1) + shift.double().view(1, -1, 1, 1, 1)
-    res = torch.randn(ref.shape, generator=g) if use_res else None
-    if use_res:
-        ref = ref + res.double()
-    if relu:
-        ref = F.relu(ref)
-    assert hiplib.msnet_conv3d_k3s2_c8_f16s_supported(d, h, w, ci, co) == 1
-    wpk = hipops.pack_conv_weight(wt.cuda(), f16s=True, stride=2)
-    wpk2 = hipops.pack_conv_weight_s2c8(wt.cuda())
-    y = hipops.conv3d_k3(_cl(x), wpk, scale.cuda(), shift.cuda(), co, stride=2, relu=relu, residual=_cl(res) if use_res else None,
-                         f16s=True, wpk_s2c8=wpk2)
-    assert tuple(_nc(y).shape) == tuple(ref.shape)
-    err = _rel(_nc(y).double(), ref)
-    y_ws = hipops.conv3d_k3(_cl(x), wpk, scale.cuda(), shift.cuda(), co, stride=2, relu=relu, residual=_cl(res) if use_res else None, f16s=True)
-    print("s2c8 %d->%d %s rel err %.2e (wave-specialised kernel: %.2e)" % (ci, co, dims, err, _rel(_nc(y_ws).double(), ref)))
-    assert err < 5e-6
