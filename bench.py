@@ -13,10 +13,13 @@ One step = one pass of the hot path over one batch of synthetic stereo pairs alr
   RCCL all-gather of the per-rank maps closes the step.  Weak scaling: every rank processes --batch-per-gpu pairs per step.
 
 Rank 0 prints ONE JSON line (contract in the task statement) extended with
-  roofline        : the dominant kernel (conv3dbn_2's stride-1 conv) -- algorithmic FLOPs / HIP-event time vs the dense fp16
-                    MFMA peak / 3 (vendor) and vs the MFMA rate measured on this device by a register-only loop;
-  roofline_volume : the matching-space volume build, HBM-bound -- 401.4 MB algorithmic per map / sum of its kernels' HIP-event
-                    times vs 8 TB/s (vendor) and vs a float4 copy measured on this device;
+  roofline        : the kernel FAMILY with the largest total time per step (at config #2 the 64->64 stride-1 convs) -- algorithmic
+                    FLOPs / HIP-event time vs the dense fp16 MFMA peak / executed MFMAs per algorithmic product (3 split-fp16, 2 in
+                    the Winograd-depth launch), vs the MFMA rate measured on this device, and the top three families (`kernels`);
+  roofline_step   : the convs' algorithmic FLOPs per map / wall time per step against the blended MFMA ceiling;
+  roofline_volume : the matching-space volume build -- 401.4 MB algorithmic per map / its HIP-event time vs 8 TB/s (vendor) and vs a
+                    float4 copy measured on this device, with what the tracked counter pass says limits it (`limiter`);
+  power           : package power over the timed region (the SMU's energy counter) and the granted shader clock (per-XCD probe);
   step_ms         : median / p10 / p90 of the K per-step times (HIP events between the steps of the timed region);
   fp32_exact      : the same step timed again with every conv on the exact fp32-input MFMA (the reference's arithmetic);
   cpu_baseline    : the CPU oracle (a port, not the reference binary) timed on this host on a bounded sample.
