@@ -340,6 +340,10 @@ def main():
                     help="torch.distributed backend (default: RCCL = 'nccl'; env MSNET_DIST_BACKEND).  'gloo' lets several ranks share "
                          "one GPU (LOCAL_RANK modulo the device count, collective through host memory): a functional run of the "
                          "world > 1 path on a 1-GPU box, not a measurement")
+    ap.add_argument("--pipeline", action="store_true",
+                    help="serving-loop mode: the volume of step k+1 is built on a side stream while step k is aggregated (two volume "
+                         "buffers; every timed step still issues one build and one aggregation).  Steps overlap, so ms_per_step is "
+                         "no longer a per-map latency -- diagnostic, not the headline")
     ap.add_argument("--wd64", action="store_true",
                     help="experiment (DESIGN 10): the 64->64 stride-1 layers as four Winograd-depth launches each -- diagnostic")
     ap.add_argument("--self-launch", action="store_true",
@@ -406,6 +410,33 @@ def main():
             for b, (l, r) in enumerate(pairs):
                 builder(l, r, out=vol[b])
         return model.forward_ndhwc(vol) if cl else model(vol)
+
+    if args.pipeline and not args.no_volume:
+        # software pipeline of a serving loop: build(k+1) on a side stream under aggregate(k); two volume buffers, events both ways
+        vols = [vol, torch.empty_like(vol)]
+        side = torch.cuda.Stream()
+        built = [torch.cuda.Event(), torch.cuda.Event()]
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        pstate = {"k": 0, "primed": False}
+
+        def enqueue_build(i):
+            side.wait_event(consumed[i])                 # the aggregation that last read this buffer (no-op before its first record)
+            with torch.cuda.stream(side):
+                for b, (l, r) in enumerate(pairs):
+                    builder(l, r, out=vols[i][b])
+                built[i].record(side)
+
+        def local_step():       # noqa: F811
+            i = pstate["k"] & 1
+            if not pstate["primed"]:
+                enqueue_build(i)
+                pstate["primed"] = True
+            enqueue_build(i ^ 1)                         # the NEXT step's volume, under this step's aggregator
+            torch.cuda.current_stream().wait_event(built[i])
+            out_ = model.forward_ndhwc(vols[i]) if cl else model(vols[i])
+            consumed[i].record()
+            pstate["k"] += 1
+            return out_
 
     def step():
         return msdist.gather_disparities(local_step(), n_total)
@@ -539,8 +570,8 @@ def main():
         conv_ms = sum(v["ms"] for k, v in prof_all.items() if k.startswith(("conv3d", "deconv3d")))
         conv_fl = sum(v["flops"] for k, v in prof_all.items() if k.startswith(("conv3d", "deconv3d")))
         line = {
-            "metric": "disparity maps/sec, 960x540 D=192 MS-GCNet fwd" if args.workload == "cfg2" else
-                      "disparity maps/sec (%s, not the headline)" % args.workload,
+            "metric": ("disparity maps/sec, 960x540 D=192 MS-GCNet fwd" if args.workload == "cfg2" and not args.pipeline else
+                       "disparity maps/sec (%s%s, not the headline)" % (args.workload, ", software-pipelined steps" if args.pipeline else "")),
             "value": maps / dt, "unit": "maps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.precision == "fp32" else "f32 (conv operands as split fp16 hi+lo, fp32 accumulate)",
@@ -548,6 +579,7 @@ def main():
             "config": {"workload": desc + ", batch=%d per GPU" % B, "global_batch": n_total,
                        "parallelism": "dp%d (rank-sharded pairs, %s all-gather of disparity maps)" % (world, msdist.backend() or "no"),
                        "includes_volume_build": not args.no_volume, "hip_graph": bool(args.graph),
+                       "pipelined_volume_build": bool(args.pipeline and not args.no_volume),
                        "volume_layout": ("ndhwc (channels-last hand-over, no layout pass)" if cl else
                                          "ncdhw (the reference's layout, one conversion pass)"),
                        "collective": ("%s all_gather_into_tensor" % ("rccl" if msdist.backend() == "nccl" else msdist.backend())
