@@ -211,7 +211,7 @@ def cpu_baseline(seed=0):
     run(32, 64, 96)
     tv, ta = run(272, 480, 96)
     return {"value": 1.0 / (tv + ta), "unit": "maps/s", "cores": torch.get_num_threads(), "kind": "port",
-            "cpu_model": _cpu_model(),
+            "cpu_model": _cpu_model(), "volume_s": tv, "aggregator_s": ta, "samples": 1,
             "sample": "one full map after a 32x64 warm-up: oracle volume build %.1fs + torch-CPU fp32 GCNet forward %.1fs "
                       "at 272x480 half-res, D'=96" % (tv, ta)}
 
@@ -330,6 +330,9 @@ def main():
                     help="layout of the volume handed from the build to the aggregator: 'ndhwc' (default) = the kernels' own "
                          "channels-last layout (VolumeBuilder(layout='ndhwc') + forward_ndhwc: no layout pass); 'ncdhw' = the "
                          "reference's layout through the drop-in forward() (one 802 MB conversion pass per map)")
+    ap.add_argument("--identity-bn", action="store_true",
+                    help="leave BatchNorm at its identity defaults (rounds 1-4); default: seeded non-identity BN statistics and "
+                         "affine terms (synthetic.randomize_bn, the recipe of the golden fixtures)")
     ap.add_argument("--precision", default="split-fp16", choices=["split-fp16", "fp32"])
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-launch HIP events (diagnostic)")
     ap.add_argument("--verbose", action="store_true")
@@ -391,12 +394,18 @@ def main():
     torch.manual_seed(0)
     if args.workload == "cfg3":
         from msnets_amd.psmnet_3dcnn import PSMNet_CostVolumeAggre
-        model = PSMNet_CostVolumeAggre(D).eval().to(dev)
+        model = PSMNet_CostVolumeAggre(D).eval()
+        if not args.identity_bn:
+            synthetic.randomize_bn(model, 0)
+        model = model.to(dev)
         vol = synthetic.random_volume((B, 64, D // 4, H // 4, W // 4), seed=rank).to(dev)
         args.no_volume = True
         cl = False
     else:
-        model = GCNet_CostVolumeAggre(D).eval().to(dev)
+        model = GCNet_CostVolumeAggre(D).eval()
+        if not args.identity_bn:
+            synthetic.randomize_bn(model, 0)
+        model = model.to(dev)
         cl = args.volume_layout == "ndhwc" and not args.no_volume
         builder = cbmv_generator.VolumeBuilder(hh + 20, wh + 20, nd, dev, layout="ndhwc" if cl else "ncdhw")
         vol = torch.empty((B,) + builder.out_shape, device=dev, dtype=torch.float32)
@@ -593,7 +602,9 @@ def main():
                                     else "torch.distributed.run" if "RANK" in os.environ else "single process"),
                        # what the headline depends on besides the code (the step is power-limited, so identical
                        # instruction streams run 5 % apart on different data and 3 % apart on different boxes)
-                       "weights": "net_init (seeded random), BatchNorm at its identity defaults -- no trained checkpoint exists offline",
+                       "weights": ("net_init (seeded random), " + ("BatchNorm at its identity defaults" if args.identity_bn else
+                                   "BatchNorm statistics and affine terms randomised (synthetic.randomize_bn, seed 0: the golden "
+                                   "fixtures' recipe)") + " -- no trained checkpoint exists offline"),
                        "range_guard_tripped": bool(guard_tripped)},
             "power": power,
             "step_ms": {"median": pct(50), "p10": pct(10), "p90": pct(90), "source": "HIP events between steps, rank 0"},
@@ -718,7 +729,35 @@ def main():
                 hipops.set_default_precision(args.precision)
                 line["fp32_exact"] = {"value": n_total * k32 / d32, "unit": "maps/s", "ms_per_step": 1e3 * d32 / k32, "steps": k32,
                                       "dtype": "f32 (exact fp32-input MFMA in every conv)"}
+        if world == 1 and not args.no_extras and args.workload != "cfg3" and not args.no_volume and not args.pipeline:
+            # the reference's module contract on the line: VolumeBuilder(layout="ncdhw") -> model(vol) = forward(cv: f32[N,8,D',H',W'])
+            # (gcnet_3dcnn.py:97, cbmv_generator.py:307-308), i.e. the route a maintainer gets by swapping the two imports
+            # (INTEGRATION.md); `value` above times the channels-last hand-over unless --volume-layout ncdhw
+            b_nc = cbmv_generator.VolumeBuilder(hh + 20, wh + 20, nd, dev, layout="ncdhw")
+            v_nc = torch.empty((B,) + b_nc.out_shape, device=dev, dtype=torch.float32)
+
+            def dropin_step():
+                for b, (l, r) in enumerate(pairs):
+                    b_nc(l, r, out=v_nc[b])
+                return msdist.gather_disparities(model(v_nc), n_total)
+
+            o_hl = step().clone()                         # the headline route's maps, same weights, same pairs
+            for _ in range(2):
+                o_nc = dropin_step()
+            torch.cuda.synchronize()
+            kd = max(5, min(10, args.steps))
+            t1 = time.perf_counter()
+            for _ in range(kd):
+                o_nc = dropin_step()
+            torch.cuda.synchronize()
+            dd = time.perf_counter() - t1
+            line["dropin_ncdhw"] = {"value": n_total * kd / dd, "unit": "maps/s", "ms_per_step": 1e3 * dd / kd, "steps": kd,
+                                    "route": "VolumeBuilder(layout='ncdhw') -> GCNet_CostVolumeAggre.forward(cv[N,8,D',H',W']): the "
+                                             "reference's module contract, one NCDHW->NDHWC pass inside forward()",
+                                    "max_abs_diff_vs_headline_route": float((o_nc - o_hl).abs().max())}
+            del v_nc, b_nc, o_nc, o_hl
         if world == 1 and not args.no_cpu_baseline:
+            msdist.restore_affinity()          # the NUMA pinning of a launched rank must not confine the CPU baseline's threads
             line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line), flush=True)
 

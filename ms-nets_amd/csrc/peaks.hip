@@ -153,11 +153,16 @@ extern "C" double msnet_peak_mfma_f16_rand(void* scratch, int iters, int shape16
 // Per XCD: one thread stores {shader-clock counter (s_memtime: ticks at the clock the power manager currently grants that XCD),
 // constant 100 MHz counter (s_memrealtime)} into slot XCC_ID of device_u64x16 (8 XCDs x 2).  The shader-clock counters of the
 // XCDs are not one counter, so a probe is a grid of single-thread workgroups -- round-robin dispatch puts some on every XCD --
-// and each writes its own XCD's slot.  Two probes on one stream bracket a region: granted clock of XCD i = d(ticks_i) / d(real_i).
+// and each writes its own XCD's slot.  Several workgroups land on one XCD: the pair is read back to back by ONE thread and
+// leaves as ONE 16-byte store, so a slot always holds a {ticks, realtime} pair from the same workgroup (whichever wrote last;
+// they are nanoseconds apart).  Two probes on one stream bracket a region: granted clock of XCD i = d(ticks_i) / d(real_i).
+typedef unsigned long long u64x2_p __attribute__((ext_vector_type(2)));
 __global__ void clock_probe_kernel(unsigned long long* out) {
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;          // hwreg(HW_REG_XCC_ID), bits 3:0
-    out[2 * xcc] = __builtin_readcyclecounter();
-    out[2 * xcc + 1] = __builtin_amdgcn_s_memrealtime();
+    u64x2_p v;
+    v.x = __builtin_readcyclecounter();
+    v.y = __builtin_amdgcn_s_memrealtime();
+    __builtin_nontemporal_store(v, reinterpret_cast<u64x2_p*>(out + 2 * xcc));   // global_store_dwordx4: one transaction
 }
 
 extern "C" int msnet_clock_probe(void* device_u64x16, msnet_stream_t stream) {

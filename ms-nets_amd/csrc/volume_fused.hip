@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <type_traits>
 
@@ -708,10 +709,22 @@ size_t volume_fast_workspace_bytes(int Hb, int Wb, int nd) {
 // stream and two events per (device, caller stream), created on first use: builds issued on DIFFERENT streams (two host
 // threads, two VolumeBuilders) never share an event; builds on one stream are ordered by that stream.  fork / join are
 // ordinary event waits, so the build stays asynchronous on the caller's stream and capturable.
-struct VolAux { hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; unsigned long long used = 0; };
+struct VolAux {
+    hipStream_t s = nullptr; hipEvent_t fork = nullptr, join = nullptr; bool ok = false; unsigned long long used = 0;
+    VolAux() = default;
+    VolAux(const VolAux&) = delete;
+    VolAux& operator=(const VolAux&) = delete;
+    ~VolAux() {                                             // HIP lets work queued on a destroyed stream finish first
+        if (fork) (void)hipEventDestroy(fork);
+        if (join) (void)hipEventDestroy(join);
+        if (s) (void)hipStreamDestroy(s);
+    }
+};
 constexpr size_t kMaxVolAux = 16;      // helper streams kept alive at once (callers that build on many short-lived streams)
-static VolAux& vol_aux(hipStream_t caller) {
-    static std::map<std::pair<int, hipStream_t>, VolAux*> aux;
+// Entries are handed out as shared_ptr: an entry that the LRU eviction drops from the table while another thread's launch
+// sequence still uses it stays alive until that sequence returns (the references handed out before were freed under it).
+static std::shared_ptr<VolAux> vol_aux(hipStream_t caller) {
+    static std::map<std::pair<int, hipStream_t>, std::shared_ptr<VolAux>> aux;
     static std::mutex mu;
     static unsigned long long tick = 0;
     std::lock_guard<std::mutex> lk(mu);
@@ -721,25 +734,19 @@ static VolAux& vol_aux(hipStream_t caller) {
     auto it = aux.find(key);
     if (it == aux.end()) {
         if (aux.size() >= kMaxVolAux) {
-            // least recently used entry goes: its helper stream is destroyed (HIP lets queued work finish first) together with
-            // its events.  A caller stream whose entry was evicted simply gets a new one on its next build.
+            // least recently used entry leaves the table; a caller stream whose entry was evicted gets a new one on its next build
             auto old = aux.begin();
             for (auto j = aux.begin(); j != aux.end(); ++j) if (j->second->used < old->second->used) old = j;
-            VolAux* v = old->second;
-            if (v->fork) (void)hipEventDestroy(v->fork);
-            if (v->join) (void)hipEventDestroy(v->join);
-            if (v->s) (void)hipStreamDestroy(v->s);
-            delete v;
             aux.erase(old);
         }
-        VolAux* x = new VolAux();
+        auto x = std::make_shared<VolAux>();
         x->ok = hipStreamCreateWithFlags(&x->s, hipStreamNonBlocking) == hipSuccess &&
                 hipEventCreateWithFlags(&x->fork, hipEventDisableTiming) == hipSuccess &&
                 hipEventCreateWithFlags(&x->join, hipEventDisableTiming) == hipSuccess;
-        it = aux.emplace(key, x).first;
+        it = aux.emplace(key, std::move(x)).first;
     }
     it->second->used = ++tick;
-    return *it->second;
+    return it->second;
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-device attribute of a kernel: set once per (device, kernel), under a lock
@@ -787,8 +794,9 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
     if (channels_last && (size_t)nd * plane * 32 > 0xfffffff0u)
         return fail("msnet_build_volume_ndhwc: the volume exceeds the 4 GB buffer-descriptor range");
     // (the channels-last feature launch needs all four matchers at once: nothing to overlap the Sobel-SAD kernels with, no helper stream)
-    static VolAux none;
-    VolAux& aux = (channels_last || !want_overlap) ? none : vol_aux(s);
+    static const std::shared_ptr<VolAux> none = std::make_shared<VolAux>();
+    const std::shared_ptr<VolAux> aux_ref = (channels_last || !want_overlap) ? none : vol_aux(s);     // alive until this call returns
+    VolAux& aux = *aux_ref;
     const bool overlap = want_overlap && aux.ok && !channels_last;
     hipStream_t sb = overlap ? aux.s : s;                  // stream of the Sobel-SAD kernels
 

@@ -29,6 +29,9 @@ def ranks_per_device():
     return _ranks_per_device
 
 
+_affinity_before = []
+
+
 def _gpu_cards():
     """amdgpu devices in /sys/class/drm, in card order (the order HIP enumerates them in on a stock node)."""
     out = []
@@ -58,25 +61,33 @@ def bind_to_gpu_numa_node(local_rank):
     node bound to, or None (single-node host, no such file, visible-device remapping that cannot be resolved: nothing done)."""
     try:
         cards = _gpu_cards()
-        vis = os.environ.get("ROCR_VISIBLE_DEVICES") or os.environ.get("HIP_VISIBLE_DEVICES")
-        if vis:
-            ids = [v.strip() for v in vis.split(",")]
-            if not all(v.isdigit() for v in ids):
-                return None
-            cards = [cards[int(v)] for v in ids if int(v) < len(cards)]
-        if not cards:
+        # any visible-device remapping (the three variables compose) makes "HIP ordinal -> drm card" a guess: do nothing then
+        if any(os.environ.get(k) for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL")):
             return None
-        node = int(open(os.path.join(cards[local_rank % len(cards)], "numa_node")).read().strip())
+        if not cards or local_rank >= len(cards):
+            return None
+        node = int(open(os.path.join(cards[local_rank], "numa_node")).read().strip())
         if node < 0:
             return None
         cpus = _parse_cpulist(open("/sys/devices/system/node/node%d/cpulist" % node).read())
-        cpus &= os.sched_getaffinity(0)
+        before = os.sched_getaffinity(0)
+        cpus &= before
         if not cpus:
             return None
         os.sched_setaffinity(0, cpus)
+        _affinity_before.append(before)
         return node
     except (OSError, ValueError, IndexError):
         return None
+
+
+def restore_affinity():
+    """Undo bind_to_gpu_numa_node (threads started afterwards -- a CPU baseline's OpenMP pool -- see every core again)."""
+    if _affinity_before:
+        try:
+            os.sched_setaffinity(0, _affinity_before.pop())
+        except OSError:
+            pass
 
 
 def init_from_env(backend=None):
@@ -93,8 +104,16 @@ def init_from_env(backend=None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
     if torch.cuda.is_available():
         ndev = torch.cuda.device_count()
-        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))
-        if local_world > ndev:
+        # Oversubscription: LOCAL_WORLD_SIZE (torchrun exports it) says how many ranks share THIS node.  Launchers that
+        # export only RANK / WORLD_SIZE / LOCAL_RANK (srun, mpirun wrappers) say nothing about it -- WORLD_SIZE counts
+        # every node -- so there only LOCAL_RANK itself can show that a rank has no device of its own.
+        if "LOCAL_WORLD_SIZE" in os.environ:
+            local_world = int(os.environ["LOCAL_WORLD_SIZE"])
+            over = local_world > ndev
+        else:
+            local_world = local + 1
+            over = local >= ndev
+        if over:
             if backend == "nccl":
                 raise RuntimeError("%d ranks on %d GPU(s): RCCL needs one device per rank (use one process per GPU, or "
                                    "MSNET_DIST_BACKEND=gloo for a functional run that shares devices)" % (local_world, ndev))

@@ -38,3 +38,19 @@ def random_volume(shape, seed=0):
     """torch.rand volume in [0,1] like real MS features (aggregator-only runs)."""
     g = torch.Generator().manual_seed(seed)
     return torch.rand(shape, generator=g)
+
+
+def randomize_bn(model, seed=0):
+    """Non-identity BatchNorm for seeded random-init weights (at its defaults BN is an identity and a BN-folding
+    defect cannot show): running_mean ~ 0.1 N(0,1), running_var and gamma ~ U(0.75, 1.25), beta ~ 0.1 N(0,1), from one seeded
+    generator in module order -- the recipe the golden fixtures were generated with (tests/golden/recipes.py)."""
+    g = torch.Generator().manual_seed(10_000 + seed)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm3d):
+                c = m.num_features
+                m.running_mean.copy_(torch.randn(c, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(c, generator=g) * 0.5 + 0.75)
+                m.weight.copy_(torch.rand(c, generator=g) * 0.5 + 0.75)
+                m.bias.copy_(torch.randn(c, generator=g) * 0.1)
+    return model

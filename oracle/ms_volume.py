@@ -16,7 +16,6 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "liboracle_matchers.so")
-_lib = None
 _u8p = np.ctypeslib.ndpointer(np.uint8, flags="C_CONTIGUOUS")
 _f32p = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
 
@@ -26,12 +25,31 @@ def build():
     return _SO
 
 
+_libs = {}
+_variant = [""]
+
+
+class variant:
+    """`with variant("refflags"):` routes every call below through liboracle_matchers_refflags.so -- the same source compiled
+    with the reference's own optimisation flags (Makefile) -- so a test can hold the two builds bit-identical."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        _variant.append(self.name)
+
+    def __exit__(self, *exc):
+        _variant.pop()
+
+
 def lib():
-    global _lib
-    if _lib is None:
-        if not os.path.exists(_SO):
+    v = _variant[-1]
+    if v not in _libs:
+        so = _SO if not v else _SO.replace(".so", "_%s.so" % v)
+        if not os.path.exists(so):
             build()
-        L = ctypes.CDLL(_SO)
+        L = ctypes.CDLL(so)
         i = ctypes.c_int
         L.oracle_census.argtypes = [_u8p, _u8p, _f32p, i, i, i, i]
         L.oracle_ncc.argtypes = [_u8p, _u8p, _f32p, i, i, i, i]
@@ -43,8 +61,8 @@ def lib():
         for f in ("oracle_census", "oracle_ncc", "oracle_zsad", "oracle_sobel", "oracle_sadsob", "oracle_swap_axes",
                   "oracle_extract_likelihood"):
             getattr(L, f).restype = None
-        _lib = L
-    return _lib
+        _libs[v] = L
+    return _libs[v]
 
 
 def _img(a):

@@ -180,3 +180,52 @@ def test_three_operation_division_is_the_ieee_quotient():
     r = (e.astype(np.float64) - q.astype(np.float64) * den.astype(np.float64)).astype(f32)
     got = (q.astype(np.float64) + r.astype(np.float64) * rb.astype(np.float64)).astype(f32)
     assert np.array_equal(got, e / den)
+
+
+def _cpu_has(*flags):
+    try:
+        words = set(open("/proc/cpuinfo").read().split())
+    except OSError:
+        return False
+    return all(f in words for f in flags)
+
+
+@pytest.mark.skipif(not _cpu_has("avx2", "fma"), reason="the reference's -march=core-avx2 build needs AVX2 + FMA")
+def test_oracle_is_independent_of_the_reference_compile_flags():
+    """The one thing a line-by-line restatement can still get wrong is arithmetic that depends on how it was COMPILED.  The
+    reference is built with -O3 -msse4.1 -march=core-avx2 -funroll-loops and g++'s default FMA contraction
+    (src/cpp/CMakeLists.txt:11); the oracle with -O2 -ffp-contract=off.  Both builds of the restatement must return the same
+    bits on every image kind of the GPU parity suite (tests/test_gpu_volume.py CASES, the full 292x500x96 pair included):
+    raw costs of all four matchers, Sobel, and all eight volume channels.  (Found by this test: the raw NCC cost's exact
+    zeros change SIGN with FMA contraction -- see below; nothing else moves.)  The oracle stays PARITY UNPINNED (no
+    reference binary can be built here); this only removes compile-flag dependence from the list of ways it could differ."""
+    from test_gpu_volume import CASES, _pair
+
+    def everything(l, r, nd):
+        sl, sr = O.sobel(l), O.sobel(r)
+        raw = {"census": O.census(l, r, nd, 11), "ncc": O.nccNister(l, r, nd, 3), "zsad": O.zsad(l, r, nd, 5), "sobel_l": sl,
+               "sobel_r": sr, "sadsob": O.sadsob(sl, sr, nd, 5)}
+        if min(l.shape) > 20:
+            vol = O.build_ms_volume(l, r, nd)
+            for c in range(8):
+                raw["volume_ch%d" % c] = vol[c]
+        return raw
+
+    for H, W, nd, seed, kind in CASES:
+        l, r = _pair(H, W, nd, seed, kind)
+        a = everything(l, r, nd)
+        with O.variant("refflags"):
+            b = everything(l, r, nd)
+        for k in a:
+            bad = a[k].view(np.uint32) != b[k].view(np.uint32)
+            if k == "ncc":
+                # The one flag-dependent expression of the path: matchers.cpp:200 negates (sqwin*lD - Al*Ar) before the two
+                # multiplies.  Where that difference is exactly 0 (a window pair with zero covariance) plain evaluation
+                # gives -0.0, an FMA-contracting build folds the negation into vfnmadd (Al*Ar - sqwin*lD) and gives +0.0.
+                # Which one the reference's own binary returns depends on its compiler; the VALUE is 0 either way and
+                # every consumer ((1 + clip)/2, (c - min)^2) maps both to the same bits -- the volume channels below are
+                # compared bit for bit with no such exception.
+                assert np.array_equal(a[k], b[k]) and not a[k][bad].any(), "ncc differs by more than the sign of a zero"
+                continue
+            assert not bad.any(), "%s %dx%d D'=%d: %s differs in %d values between the two oracle builds" % (
+                kind, H, W, nd, k, int(bad.sum()))
