@@ -504,10 +504,23 @@ def main():
     per_step = sorted(step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps))
     guard_tripped = model._forced_precision is not None           # the fp16-range guard moved the module to fp32 (hipops)
 
+    dt_local = dt
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if msdist.backend() == "nccl" else "cpu")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
+    # one row per rank, through the process group itself: a SCALE run then says on its own line which device, which NUMA node and
+    # which local time every rank had ("did RCCL see N ranks on N devices" is answerable from the JSON, no log archaeology)
+    props = torch.cuda.get_device_properties(dev)
+    mine_row = {"rank": rank, "local_rank": local, "device": props.name, "gcn_arch": getattr(props, "gcnArchName", None),
+                "pci_bus_id": "%04x:%02x:%02x" % (getattr(props, "pci_domain_id", 0), getattr(props, "pci_bus_id", 0),
+                                                   getattr(props, "pci_device_id", 0)),
+                "numa_node_bound": numa_node, "pairs_per_step": B, "ms_per_step_local": 1e3 * dt_local / args.steps}
+    if msdist.backend():
+        per_rank = [None] * world
+        torch.distributed.all_gather_object(per_rank, mine_row)
+    else:
+        per_rank = [mine_row]
 
     # post-pass (untimed, every rank: a step contains the collective): all families under HIP events
     POST_STEPS = 3
@@ -598,6 +611,8 @@ def main():
                        "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if msdist.backend() == "nccl" else None),
                        "ranks_per_device": msdist.ranks_per_device(),
                        "numa_node_bound": numa_node,
+                       "per_rank": per_rank,
+                       "distinct_devices": len({r_["pci_bus_id"] for r_ in per_rank}),
                        "launcher": ("bench.py self-launch (child torch.distributed.run)" if os.environ.get("MSNET_BENCH_SELF_LAUNCHED")
                                     else "torch.distributed.run" if "RANK" in os.environ else "single process"),
                        # what the headline depends on besides the code (the step is power-limited, so identical

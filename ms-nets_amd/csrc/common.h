@@ -29,6 +29,21 @@ struct LaunchScope {
     const char* name; hipStream_t stream; void* rec;
 };
 
+// The likelihood numerator exp(-(c - m)^2 / sigma) (featextract.cpp:444-449) as v_exp_f32((c - m)^2 * k), k = RN(-log2(e) / sigma)
+// formed once per launch in double.  The library route -- IEEE division by sigma (or its three-operation equivalent), then
+// expf's compensated product, rndne / ldexp range reduction and two range selects -- is 18 VALU instructions per evaluation, two
+// evaluations per likelihood element in the channels-last build; this is 4.  What it costs: three roundings on the exponent
+// instead of none, i.e. a RELATIVE error of about |x| * 2e-7 on e^x with x <= 0 -- at most 7e-8 ABSOLUTE (at x = -1) -- plus
+// v_exp_f32's own ulp, against the 2e-6 the likelihood channels are held to (GPU and glibc expf are different <= 1 ulp
+// implementations to begin with; tests/test_gpu_volume.py prints the measured maximum).  x <= 0 cannot overflow, a result below
+// 2^-126 is 0 either way, exp(-0) = 1 exactly (so den >= 1 still holds), and a sentinel cost gives exp2(-3e20) = 0 as before.
+// Every kernel that forms a likelihood uses these two functions, so the fast, generic and per-op paths agree bit for bit.
+__host__ __device__ inline float aml_scale(float sigma) { return (float)(-1.44269504088896340736 / (double)sigma); }
+__device__ __forceinline__ float aml_numerator(float c, float m, float k) {
+    const float n = c - m;
+    return __builtin_amdgcn_exp2f((n * n) * k);
+}
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail("%s: launch failed: %s", what, hipGetErrorString(e));

@@ -274,10 +274,7 @@ __global__ __launch_bounds__(256) void swap_axes_kernel(const float* __restrict_
 // extract_aml_testing: per row of D costs, m = min; den = sum_k expf(-((c_k-m)^2)/sigma) accumulated
 // sequentially in float32; out_k = expf(-((c_k-m)^2)/sigma)/den, or 0 for an all-sentinel row.
 __device__ __forceinline__ float aml_term(float c, float m, float sigma) {
-    const float num = c - m;
-    float q = num * num;
-    q = q / sigma;
-    return expf(-q);
+    return aml_numerator(c, m, aml_scale(sigma));          // (the scale is loop-invariant at every call site: one double division per thread)
 }
 
 // vol/out [P][D]; 64 rows per wave staged through LDS (row stride D+1) so global accesses are coalesced.

@@ -12,7 +12,7 @@
 //                      fully unrolled, right-image data comes from LDS strips), so each output element is written once
 //                      and expf is evaluated once per element:
 //                        pass 1  raw cost c_d for every d -> normalised cost channel (cbmv_generator.py:283-287), min
-//                        pass 2  e_d = expf(-(c_d - m)^2 / sigma), den += e_d in d order (featextract.cpp:444-447)
+//                        pass 2  e_d = exp(-(c_d - m)^2 / sigma) (aml_numerator, common.h), den += e_d in d order (featextract.cpp:444-447)
 //                        pass 3  likelihood channel e_d / den (featextract.cpp:452-458)
 //
 // HBM traffic per map: the 8 output channels (401 MB at 960x544, D=192) + the parked Sobel-SAD raw costs (50 MB written,
@@ -41,7 +41,7 @@ struct FastArgs {
     float* ml; float* mr;               // ZSAD window means
     float* sobl; float* sobr;           // Sobel images
     float* out;
-    float sigma[4], rsigma[4];          // rsigma = RN(1 / sigma), computed on the host
+    float kexp[4];                      // aml_scale(sigma) per matcher (common.h), computed on the host
     int Hb, Wb, nd, bh, bw, Hc, Wc;
 };
 
@@ -157,11 +157,12 @@ __global__ __launch_bounds__(256) void sadsob_bandsum_kernel(FastArgs a, float* 
         const int r0 = b == 0 ? 0 : first + (b - 1) * R, r1 = first + b * R;      // image rows [r0, r1)
         const float* pl = a.sobl + j;
         const float* pr = a.sobr + j - d;
-        float v[R];
+        float vl[R], vr[R];                                // (raw loads, a scheduling fence, then the arithmetic: see sadsob_band_kernel)
 #pragma unroll
-        for (int k = 0; k < R; ++k) { const int row = min(r0 + k, H - 1); v[k] = fabsf(pl[row * W] - pr[row * W]); }
+        for (int k = 0; k < R; ++k) { const int row = min(r0 + k, H - 1); vl[k] = pl[row * W]; vr[k] = pr[row * W]; }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int k = 0; k < R; ++k) if (r0 + k < r1) sum += v[k];
+        for (int k = 0; k < R; ++k) if (r0 + k < r1) sum += fabsf(vl[k] - vr[k]);
     }
     bs[((size_t)d * nbands + b) * LS + c] = sum;
 }
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(NT) void sadsob_band_kernel(FastArgs a, const float
             float t[kMaxBands];                            // all loads in flight at once (a dependent chain would pay 26 L2 latencies)
 #pragma unroll
             for (int b = 0; b < kMaxBands; ++b) t[b] = q[(size_t)min(b, band) * LS];
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int b = 0; b < kMaxBands; ++b) if (b <= band) run += t[b];       // exact integers (see above)
         }
@@ -202,15 +204,20 @@ __global__ __launch_bounds__(NT) void sadsob_band_kernel(FastArgs a, const float
         const float* pr = a.sobr + (live ? j - d : 0);
 #pragma unroll
         for (int i0 = 0; i0 < NR; i0 += 16) {
-            float v[16];
+            float vl[16], vr[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                if (i0 + k < NR) { const int row = min(i_lo - 1 + i0 + k, H - 1); v[k] = fabsf(pl[row * W] - pr[row * W]); }
+                if (i0 + k < NR) { const int row = min(i_lo - 1 + i0 + k, H - 1); vl[k] = pl[row * W]; vr[k] = pr[row * W]; }
             }
+            // all 32 loads of the batch are requested before the first dependent add: without the fence the machine scheduler is free
+            // to pair each load with its add (load, load, s_waitcnt vmcnt(0), add ...) -- one L2 round trip per row instead of one per
+            // batch -- and did so the moment an unrelated edit moved its register-pressure estimate (45 -> 62 us per map)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
-                if (i0 + k < NR) { run = live ? v[k] + run : 0.f; S[(i0 + k) * LS + c] = run; }
+                if (i0 + k < NR) { run = live ? fabsf(vl[k] - vr[k]) + run : 0.f; S[(i0 + k) * LS + c] = run; }
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     __syncthreads();
@@ -300,12 +307,7 @@ __device__ __forceinline__ float norm_cost(int M, float c) {
     return fminf(fmaxf(c, 0.f), 8192.f) * (1.f / 8192.f);                           // :286-287 (x / 2^13 is exact)
 }
 
-__device__ __forceinline__ float aml_e(float c, float m, float sigma, float rsigma) {
-    const float num = c - m;
-    float q = num * num;
-    q = div_rn(q, sigma, rsigma);
-    return expf(-q);
-}
+__device__ __forceinline__ float aml_e(float c, float m, float kexp) { return aml_numerator(c, m, kexp); }
 
 // M: 0 census, 1 NCC, 2 Sobel-SAD (raw costs parked by sadsob_band_kernel), 3 ZSAD.
 // ND: compile-time bound on the disparities (register array); nd <= ND, nd % 8 == 0.
@@ -516,7 +518,7 @@ __device__ __forceinline__ void features_px(const FastArgs& a, unsigned char* sm
         }
     }
     // ---- pass 2: likelihood numerators, denominator accumulated in d order
-    const float sigma = a.sigma[M], rsigma = a.rsigma[M];
+    const float kexp = a.kexp[M];
     float den = 0.f;
 #pragma unroll
     for (int d0 = 0; d0 < ND; d0 += 8) {
@@ -524,7 +526,7 @@ __device__ __forceinline__ void features_px(const FastArgs& a, unsigned char* sm
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int d = d0 + u;
-                const float e = aml_e(c[d], m, sigma, rsigma);
+                const float e = aml_e(c[d], m, kexp);
                 den += e;
                 c[d] = e;
             }
@@ -571,8 +573,8 @@ __global__ __launch_bounds__(256, 3) void features4_kernel(FastArgs a, int zbase
 // pixels with the D' raw costs in registers exactly as features_px does (same code: stage_right / raw_costs), then the four
 // waves meet per group of eight disparities in an LDS tile [8 d][8 ch][64 px] and the 256 threads write it out as whole
 // voxels: every store instruction of a wave covers 1 KB of contiguous output.  Both channels of a matcher must exist at the
-// same time for that, so the likelihood numerator expf(-(c_d - m)^2 / sigma) is evaluated twice (once for the denominator,
-// once for the value) instead of being kept in the cost's register -- same bits, one more expf per element.
+// same time for that, so the likelihood numerator exp(-(c_d - m)^2 / sigma) is evaluated twice (once for the denominator,
+// once for the value) instead of being kept in the cost's register -- same bits, four more instructions per element (common.h).
 constexpr int kClPitch = 72;       // floats per LDS tile row: 64 pixels + 8, so that the two half-voxel readers of a pixel (rows
                                    // 4 apart: 4 * 72 = 288 = 32 mod 64) fall on disjoint bank halves
 template <int ND> constexpr size_t features_cl_strip_bytes() {
@@ -601,14 +603,14 @@ __device__ __forceinline__ void features_cl_wave(const FastArgs& a, unsigned cha
     for (int d = 0; d < ND; ++d)
         if (d < nd && c[d] < m) m = c[d];
     // ---- pass 2: the denominator, accumulated in d order (featextract.cpp:444-447)
-    const float sigma = a.sigma[M], rsigma = a.rsigma[M];
+    const float kexp = a.kexp[M];
     float den = 0.f;
 #pragma unroll
     for (int d0 = 0; d0 < ND; d0 += 8) {
         if (d0 < nd) {
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                den += aml_e(c[d0 + u], m, sigma, rsigma);
+                den += aml_e(c[d0 + u], m, kexp);
                 if (u & 1) __builtin_amdgcn_sched_barrier(0);      // two expf in flight, not eight: all ND costs stay live here
             }
         }
@@ -638,7 +640,7 @@ __device__ __forceinline__ void features_cl_wave(const FastArgs& a, unsigned cha
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int d = d0 + u;
-                const float e = aml_e(c[d], m3, sigma, rsigma);
+                const float e = aml_e(c[d], m3, kexp);
                 buf[(u * 8 + M) * kClPitch + lane] = norm_cost(M, c[d]);
                 buf[(u * 8 + 4 + M) * kClPitch + lane] = dead ? 0.f : div_rn(e, den, rden);
                 if (u & 1) __builtin_amdgcn_sched_barrier(0);
@@ -777,8 +779,7 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
     const int Hc_ws = Hb > 12 ? Hb - 12 : 1;               // the carve below uses the workspace function's own bounds
     float* park_ws = (float*)(((uintptr_t)(ck + (size_t)nd * cdiv(Hc_ws, kBandRMin) * band_ls(Wb)) + 255) & ~(uintptr_t)255);
     a.out = out;
-    a.sigma[0] = p.cens_sigma; a.sigma[1] = p.ncc_sigma; a.sigma[2] = p.sad_sigma; a.sigma[3] = p.sad_sigma;
-    for (int k = 0; k < 4; ++k) a.rsigma[k] = 1.f / a.sigma[k];
+    a.kexp[0] = aml_scale(p.cens_sigma); a.kexp[1] = aml_scale(p.ncc_sigma); a.kexp[2] = aml_scale(p.sad_sigma); a.kexp[3] = aml_scale(p.sad_sigma);
     a.Hb = Hb; a.Wb = Wb; a.nd = nd; a.bh = p.border_h; a.bw = p.border_w;
     a.Hc = Hb - 2 * p.border_h; a.Wc = Wb - 2 * p.border_w;
     const size_t plane = (size_t)a.Hc * a.Wc;

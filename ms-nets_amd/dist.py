@@ -81,6 +81,17 @@ def bind_to_gpu_numa_node(local_rank):
         return None
 
 
+def oversubscribed(env, local_rank, ndev):
+    """(ranks of this node outnumber its devices?, ranks on this node as far as the launcher says).  LOCAL_WORLD_SIZE (torchrun
+    exports it) counts the ranks of THIS node.  Launchers that export only RANK / WORLD_SIZE / LOCAL_RANK (srun, mpirun
+    wrappers) say nothing about it -- WORLD_SIZE counts every node -- so there only LOCAL_RANK itself can show that a rank has
+    no device of its own."""
+    if "LOCAL_WORLD_SIZE" in env:
+        lw = int(env["LOCAL_WORLD_SIZE"])
+        return lw > ndev, lw
+    return local_rank >= ndev, local_rank + 1
+
+
 def restore_affinity():
     """Undo bind_to_gpu_numa_node (threads started afterwards -- a CPU baseline's OpenMP pool -- see every core again)."""
     if _affinity_before:
@@ -104,15 +115,7 @@ def init_from_env(backend=None):
         backend = "nccl" if torch.cuda.is_available() else "gloo"   # "nccl" is RCCL on ROCm
     if torch.cuda.is_available():
         ndev = torch.cuda.device_count()
-        # Oversubscription: LOCAL_WORLD_SIZE (torchrun exports it) says how many ranks share THIS node.  Launchers that
-        # export only RANK / WORLD_SIZE / LOCAL_RANK (srun, mpirun wrappers) say nothing about it -- WORLD_SIZE counts
-        # every node -- so there only LOCAL_RANK itself can show that a rank has no device of its own.
-        if "LOCAL_WORLD_SIZE" in os.environ:
-            local_world = int(os.environ["LOCAL_WORLD_SIZE"])
-            over = local_world > ndev
-        else:
-            local_world = local + 1
-            over = local >= ndev
+        over, local_world = oversubscribed(os.environ, local, ndev)
         if over:
             if backend == "nccl":
                 raise RuntimeError("%d ranks on %d GPU(s): RCCL needs one device per rank (use one process per GPU, or "

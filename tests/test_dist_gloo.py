@@ -67,3 +67,17 @@ def test_single_process_is_identity():
     x = torch.rand(2, 3, 4)
     assert msdist.gather_disparities(x, 2) is x
     assert msdist.shard_indices(5, 0, 1) == [0, 1, 2, 3, 4]
+
+
+def test_oversubscription_rule_per_launcher_env():
+    """a multi-node launch that exports RANK / WORLD_SIZE / LOCAL_RANK but no LOCAL_WORLD_SIZE (srun, mpirun
+    wrappers) must not be refused because the GLOBAL world size exceeds one node's device count."""
+    from msnets_amd.dist import oversubscribed
+    # torchrun on one 8-GPU node, and two ranks forced onto one device
+    assert oversubscribed({"LOCAL_WORLD_SIZE": "8"}, 7, 8) == (False, 8)
+    assert oversubscribed({"LOCAL_WORLD_SIZE": "2"}, 1, 1) == (True, 2)
+    # srun over 4 nodes x 8 GPUs: WORLD_SIZE = 32, no LOCAL_WORLD_SIZE; every local rank 0..7 has its own device
+    for lr in range(8):
+        assert oversubscribed({"WORLD_SIZE": "32", "RANK": str(8 + lr), "LOCAL_RANK": str(lr)}, lr, 8)[0] is False
+    # the same launcher with more local ranks than devices is still caught, by the rank that has no device
+    assert oversubscribed({"WORLD_SIZE": "32"}, 8, 8)[0] is True

@@ -106,6 +106,20 @@ def test_bench_self_launch(gpu):
     assert d["config"]["world_size"] == 1 and d["config"]["rccl_version"]
     assert d["config"]["launcher"].startswith("bench.py self-launch")
     assert "roofline_step" in d and 0 < d["roofline_step"]["frac"] < 1
+    pr = d["config"]["per_rank"]
+    assert len(pr) == 1 and pr[0]["rank"] == 0 and pr[0]["pairs_per_step"] == 2 and pr[0]["ms_per_step_local"] > 0
+    assert d["config"]["distinct_devices"] == 1 and "gfx950" in (pr[0]["gcn_arch"] or "")
+
+
+def test_bench_cfg4_share_under_rccl(gpu):
+    """Config #4's per-rank share (960x540, D=192, batch 4 per GPU) through the real RCCL process group on the one rank a 1-GPU
+    box has: four volume builds + one batch-4 forward per step, the all-gather of [4, 544, 960] maps on the device, and
+    bench.py's own ordering check (gathered[i] == local map of sample i) in front of the timed region."""
+    d = _run("--self-launch", "--no-cpu-baseline", "--no-extras", "--batch-per-gpu", "4", "--steps", "3", "--warmup", "1")
+    assert d["n_gpus"] == 1 and d["config"]["global_batch"] == 4 and d["value"] > 0
+    assert d["config"]["collective"] == "rccl all_gather_into_tensor" and d["config"]["dist_backend"] == "nccl"
+    assert d["config"]["per_rank"][0]["pairs_per_step"] == 4
+    assert "not the headline" not in d["metric"]            # cfg2's shape: the headline metric at another batch size
 
 
 def test_bench_roofline_step_and_profile_facts(gpu):
@@ -162,3 +176,6 @@ def test_bench_world2_on_one_gpu(gpu):
     assert d["config"]["dist_backend"] == "gloo" and d["config"]["ranks_per_device"] == 2
     assert d["config"]["collective"].startswith("gloo") and d["value"] > 0
     assert d["config"]["launcher"].startswith("bench.py self-launch")
+    pr = d["config"]["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and sorted(r["pairs_per_step"] for r in pr) == [1, 2]
+    assert d["config"]["distinct_devices"] == 1                  # both ranks on the box's one GPU (gloo only)

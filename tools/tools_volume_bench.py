@@ -1,42 +1,49 @@
-"""Times the fused matching-space volume build at a benchmark shape (HIP events via the library's own per-launch
-profiler) and prints the per-kernel split.  Also the workload of the volume PMC passes (tools_pmc_volume.sh).
-   python tools_volume_bench.py [cfg2|cfg5|cfg1] [reps] [ndhwc]"""
-import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+"""Volume build alone, in a loop: per-kernel microseconds per map from the library's own HIP events (msnet_prof_*).
+    python tools/tools_volume_bench.py [cfg2|cfg5|cfg1] [reps] [ndhwc|ncdhw]      (MSNET_HIP_LIB=... picks another build of the ABI)
+Also prints the likelihood channels' max |difference| against the oracle on a 68x100, D'=16 pair (the AML tolerance gate)."""
+import os
+import sys
+
+import numpy as np
 import torch
-import msnets_amd
-from msnets_amd import _lib, cbmv_generator, synthetic
 
-SHAPES = {"cfg2": (272, 480, 96), "cfg5": (192, 624, 96), "cfg1": (128, 256, 32)}
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+import msnets_amd  # noqa: E402,F401
+from msnets_amd import _lib, cbmv_generator, synthetic  # noqa: E402
 
-if __name__ == "__main__":
-    name = next((a for a in sys.argv[1:] if a in SHAPES), "cfg2")
-    reps = next((int(a) for a in sys.argv[1:] if a.isdigit()), 20)
-    hh, wh, nd = SHAPES[name]
-    dev = torch.device("cuda")
+SHAPES = {"cfg1": (128, 256, 32), "cfg2": (272, 480, 96), "cfg5": (192, 624, 96)}
+
+
+def main():
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "cfg2"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    layout = sys.argv[3] if len(sys.argv) > 3 else "ndhwc"
+    hh, wh, nd = SHAPES[cfg]
+    dev = torch.device("cuda:0")
     l, r, _ = synthetic.stereo_pair(hh, wh, nd, seed=0)
     l, r = torch.from_numpy(l).to(dev), torch.from_numpy(r).to(dev)
-    layout = "ndhwc" if "ndhwc" in sys.argv[1:] else "ncdhw"
-    vb = cbmv_generator.VolumeBuilder(hh + 20, wh + 20, nd, dev, layout=layout)
-    out = torch.empty(vb.out_shape, device=dev)
+    b = cbmv_generator.VolumeBuilder(hh + 20, wh + 20, nd, dev, layout=layout)
+    out = torch.empty(b.out_shape, device=dev, dtype=torch.float32)
     for _ in range(3):
-        vb(l, r, out=out)
+        b(l, r, out=out)
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
+    _lib.prof_enable(True, None)
     for _ in range(reps):
-        vb(l, r, out=out)
-    e1.record(); torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
-    alg = 4.0 * 8 * nd * hh * wh + 2.0 * (hh + 20) * (wh + 20)
-    print("%s [%s] volume build: %.3f ms per map back to back = %.0f GB/s algorithmic (%.1f MB)" % (name, layout, ms, alg / ms / 1e6, alg / 1e6))
-    _lib.prof_enable(True)
-    for _ in range(reps):
-        vb(l, r, out=out)
+        b(l, r, out=out)
     torch.cuda.synchronize()
     _lib.prof_enable(False)
-    tot = 0.0
-    for k, v in sorted(_lib.prof_collect().items(), key=lambda kv: -kv[1]["ms"]):
-        print("  %-22s %8.1f us per map" % (k, 1e3 * v["ms"] / reps))
-        tot += v["ms"] / reps
-    print("  sum of kernels %.1f us = %.0f GB/s algorithmic" % (1e3 * tot, alg / tot / 1e6))
+    prof = _lib.prof_collect()
+    row = {k: 1e3 * v["ms"] / reps for k, v in sorted(prof.items())}
+    print("%s %s lib=%s  " % (cfg, layout, os.path.basename(_lib.LIB_PATH)) + "  ".join("%s %.1f us" % kv for kv in row.items()), flush=True)
+    # AML deviation against the oracle (CPU libm expf), small pair
+    from oracle import ms_volume as O
+    ls, rs, _ = synthetic.stereo_pair(48, 80, 16, seed=0)
+    got = cbmv_generator.build_ms_volume(torch.from_numpy(ls).to(dev), torch.from_numpy(rs).to(dev), 16).cpu().numpy()
+    ref = O.build_ms_volume(ls, rs, 16)
+    print("  small pair: cost channels bit-equal %s, likelihood max|diff| %.3e" % (
+        bool((got[:4].view(np.uint32) == ref[:4].view(np.uint32)).all()), float(np.abs(got[4:] - ref[4:]).max())), flush=True)
+
+
+if __name__ == "__main__":
+    main()
