@@ -400,7 +400,11 @@ def main():
         model = model.to(dev)
         vol = synthetic.random_volume((B, 64, D // 4, H // 4, W // 4), seed=rank).to(dev)
         args.no_volume = True
-        cl = False
+        # (nothing builds a 64-plane volume on this path -- the reference's PSMNet features are out of scope -- so the synthetic
+        # volume is simply handed over in either layout: channels-last through forward_ndhwc, or the reference's NCDHW through forward)
+        cl = args.volume_layout == "ndhwc"
+        if cl:
+            vol = vol.permute(0, 2, 3, 4, 1).contiguous()
     else:
         model = GCNet_CostVolumeAggre(D).eval()
         if not args.identity_bn:

@@ -150,6 +150,11 @@ int msnet_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, int D, int 
                          msnet_stream_t stream);
 int msnet_ndhwc_to_ncdhw(const float* src, float* dst, int N, int C, int D, int H, int W,
                          msnet_stream_t stream);
+/* Range check of a module input that already IS channels-last (no conversion pass to carry it): one read of `count` floats
+ * (16-byte aligned, count % 4 == 0); raises bit 1 of the calling thread's overflow word (msnet_set_overflow_flag) when a value
+ * is outside the split-fp16 kernels' range (|x| >= 32752) or not finite.  A no-op without a registered word.  Entry of
+ * PSMNet_CostVolumeAggre.forward_ndhwc for the reference's 64-plane volume (psmnet_3dcnn.py:126-131). */
+int msnet_check_input_range(const float* x, size_t count, msnet_stream_t stream);
 
 /* Weight repacking into the MFMA operand order used by the conv kernels.
  * conv:   w f32[Co][Ci][3][3][3] (nn.Conv3d.weight)           -> packed, msnet_packed_weight_floats(Ci,Co) floats

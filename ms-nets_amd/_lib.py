@@ -52,6 +52,7 @@ SIGNATURES = {
     "msnet_preprocess_image": (c_int, [P, c_int, c_int, c_int, c_int, c_int, ctypes.POINTER(ctypes.c_double), P, P, P]),
     "msnet_ncdhw_to_ndhwc": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_ndhwc_to_ncdhw": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "msnet_check_input_range": (c_int, [P, c_size_t, P]),
     "msnet_packed_weight_floats": (c_size_t, [c_int, c_int]),
     "msnet_pack_conv_weight": (c_int, [P, P, c_int, c_int, P]),
     "msnet_pack_deconv_weight": (c_int, [P, P, c_int, c_int, P]),

@@ -81,9 +81,42 @@ __global__ __launch_bounds__(256) void nsc_to_ncs_kernel(const float* __restrict
         if (tid < cnt) dp[(size_t)c * S + tid] = tile[c * LS + tid];
 }
 
+// Read-only range check of a channels-last module input (what ncs_to_nsc_kernel does on the way for an NCDHW input): raises
+// bit 1 of the overflow word if any |x| >= 32752 or any x is inf / NaN.  n4 = number of float4.
+typedef unsigned u32x4_p __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned mag4(u32x4_p v) {
+    v &= 0x7fffffffu;
+    return max(max(v.x, v.y), max(v.z, v.w));
+}
+__global__ __launch_bounds__(256) void input_range_kernel(const u32x4_p* __restrict__ x, size_t n4, unsigned* oflag) {
+    unsigned amax = 0u;
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n4; i += 4 * stride) {         // four independent 16-byte loads in flight per thread
+        const u32x4_p v0 = __builtin_nontemporal_load(x + i), v1 = __builtin_nontemporal_load(x + i + stride);
+        const u32x4_p v2 = __builtin_nontemporal_load(x + i + 2 * stride), v3 = __builtin_nontemporal_load(x + i + 3 * stride);
+        amax = max(max(amax, mag4(v0)), max(max(mag4(v1), mag4(v2)), mag4(v3)));
+    }
+    for (; i < n4; i += stride) amax = max(amax, mag4(x[i]));
+    if (oflag && amax >= 0x46ffe000u) atomicOr(oflag, 2u);
+}
+
 }  // namespace msnet
 
 using namespace msnet;
+
+extern "C" int msnet_check_input_range(const float* x, size_t count, msnet_stream_t stream) {
+    if (!x) return fail("msnet_check_input_range: null pointer");
+    if (count == 0 || count % 4 || ((uintptr_t)x & 15)) return fail("msnet_check_input_range: %zu floats (a 16-byte aligned multiple of 4)", count);
+    unsigned* of = overflow_flag();
+    if (!of) return 0;                                     // no guard registered on this thread: nothing to report to
+    hipStream_t s = (hipStream_t)stream;
+    const size_t n4 = count / 4;
+    const unsigned blocks = (unsigned)((n4 + 1023) / 1024 < 4096 ? (n4 + 1023) / 1024 : 4096);
+    LaunchScope ls("input_range_check", s, 0, 4.0 * count);
+    hipLaunchKernelGGL(input_range_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const u32x4_p*>(x), n4, of);
+    return check_launch("msnet_check_input_range");
+}
 
 extern "C" size_t msnet_packed_weight_floats(int Ci, int Co) { return (size_t)27 * Ci * Co; }
 

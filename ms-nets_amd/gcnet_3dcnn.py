@@ -167,9 +167,13 @@ class GCNet_CostVolumeAggre(hipops.DeviceStateMixin, nn.Module):
             if channels_last:
                 if p1.f16s and cv.shape[4] == 8 and p1.co in (32, 64):
                     x = hipops.conv3d_c8_in(cv, p1.wpk, p1.scale, p1.shift, p1.co, relu=True)     # range check of the input inside
+                elif not p1.f16s:
+                    # fp32 precision: the volume already is the fp32 kernels' input layout and there is no fp16 range to guard
+                    # (this branch used to permute + convert -- two passes over the volume -- for nothing)
+                    x = conv(cv.contiguous(), "conv3dbn_1")
                 else:
-                    # (16-channel volumes, fp32 precision: no input-checking first-layer kernel -- the check rides on a copy)
-                    x = conv(hipops.ncdhw_to_ndhwc(cv.permute(0, 4, 1, 2, 3).contiguous()), "conv3dbn_1")
+                    # (16-channel volumes on split-fp16: no input-checking first-layer kernel -- one read-only range pass in front)
+                    x = conv(hipops.check_input_range(cv), "conv3dbn_1")
             elif p1.f16s and cv.shape[1] == 8 and p1.co in (32, 64) and FUSE_INPUT_LAYOUT:
                 # the first layer reads the NCDHW volume itself: no layout-conversion pass over the 401 MB
                 x = tap("conv3dbn_1", hipops.conv3d_c8_ncdhw(cv, p1.wpk, p1.scale, p1.shift, p1.co, relu=True))

@@ -305,6 +305,15 @@ def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16
     return y
 
 
+def check_input_range(x):
+    """fp16-range check of a channels-last module input (RangeGuard.INPUT), one read-only pass; returns x (contiguous)."""
+    x = require_gpu_f32(x, "x").contiguous()
+    if x.numel() % 4 == 0 and x.data_ptr() % 16 == 0:
+        check(_lib.load().msnet_check_input_range(ptr(x), x.numel(), stream_ptr()), "msnet_check_input_range")
+        return x
+    raise ValueError("check_input_range: %d floats at %#x (needs a 16-byte aligned multiple of 4)" % (x.numel(), x.data_ptr()))
+
+
 def conv3d_c8_ncdhw(x, wpk, scale, shift, co, relu=False):
     """First layer straight from the NCDHW volume x [N,8,D,H,W] (no layout-conversion pass) -> NDHWC [N,D,H,W,co]; split-fp16."""
     x = require_gpu_f32(x, "x")

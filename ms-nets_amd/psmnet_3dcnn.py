@@ -131,8 +131,10 @@ class PSMNet_CostVolumeAggre(hipops.DeviceStateMixin, nn.Module):
         if channels_last:                    # forward_ndhwc: the 8-plane MS volume as VolumeBuilder(layout="ndhwc") writes it
             if p0.f16s and cost.shape[4] == 8 and p0.co in (32, 64):
                 c0 = conv(hipops.conv3d_c8_in(cost, p0.wpk, p0.scale, p0.shift, p0.co, relu=True), "dres0.2")
-            else:                            # (fp32 precision / other widths: the input range check rides on a copy)
-                c0 = conv(conv(hipops.ncdhw_to_ndhwc(cost.permute(0, 4, 1, 2, 3).contiguous()), "dres0.0"), "dres0.2")
+            elif not p0.f16s:                # fp32 precision: already the kernels' layout, no fp16 range to guard
+                c0 = conv(conv(cost.contiguous(), "dres0.0"), "dres0.2")
+            else:                            # (other widths on split-fp16, the reference's 64 planes: one read-only range pass in front)
+                c0 = conv(conv(hipops.check_input_range(cost), "dres0.0"), "dres0.2")
         elif FUSE_INPUT_LAYOUT and p0.f16s and cost.shape[1] == 8 and p0.co in (32, 64):      # the MS volume: first layer straight from NCDHW
             c0 = conv(hipops.conv3d_c8_ncdhw(cost, p0.wpk, p0.scale, p0.shift, p0.co, relu=True), "dres0.2")
         else:

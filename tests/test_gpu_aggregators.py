@@ -1167,8 +1167,8 @@ def test_winograd_depth_on_channel_slices(gpu):
 
 def test_psmnet_forward_ndhwc_equals_forward(gpu):
     """PSMNet_CostVolumeAggre(in_planes=8).forward_ndhwc on the channels-last MS volume == forward on the NCDHW volume, bit for bit
-    (end to end from two images through VolumeBuilder(layout="ndhwc") at quarter resolution); the 64-plane module takes the
-    copying route and agrees as well."""
+    (end to end from two images through VolumeBuilder(layout="ndhwc") at quarter resolution); the 64-plane module (the
+    reference's own width) reads its channels-last input in place behind one read-only range pass and agrees as well."""
     from msnets_amd import cbmv_generator as cg, synthetic
     _, P = _our_classes()
     left, right, _ = synthetic.stereo_pair(32, 48, 16, seed=9)
@@ -1181,7 +1181,16 @@ def test_psmnet_forward_ndhwc_equals_forward(gpu):
     torch.manual_seed(32)
     m64 = P(32).eval().cuda()
     x = torch.rand(1, 64, 8, 16, 24).cuda()
-    assert torch.equal(m64.forward_ndhwc(x.permute(0, 2, 3, 4, 1).contiguous()), m64(x))
+    good = m64(x).clone()
+    assert torch.equal(m64.forward_ndhwc(x.permute(0, 2, 3, 4, 1).contiguous()), good)
+    # the 64-plane channels-last input has no conversion pass to carry the fp16-range check: msnet_check_input_range reads it once
+    for bad_value in (float("nan"), float("inf"), 4e4):
+        bad = x.clone()
+        bad[0, 17, 3, 5, 7] = bad_value
+        with pytest.warns(RuntimeWarning, match="module input"):
+            m64.forward_ndhwc(bad.permute(0, 2, 3, 4, 1).contiguous())
+        assert m64._forced_precision is None                              # a bad sample does not move the module to fp32
+    assert torch.equal(m64.forward_ndhwc(x.permute(0, 2, 3, 4, 1).contiguous()), good)
     with pytest.raises(ValueError):
         m.forward_ndhwc(vol.unsqueeze(0))
 
