@@ -3,6 +3,7 @@ C-ABI shared object (include/msnet_hip.h) that is loaded with ctypes.
 
     python -m ms-nets_amd.build            # or: from __graft_entry__ import build; build()
 """
+import hashlib
 import os
 import subprocess
 import sys
@@ -44,42 +45,72 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def _stale(target, deps):
-    if not os.path.exists(target):
+def _digest(paths, extra=()):
+    """sha256 over the CONTENT of the given files (+ the command line): what an object file was compiled from."""
+    h = hashlib.sha256()
+    for p in paths:
+        with open(p, "rb") as f:
+            h.update(hashlib.sha256(f.read()).digest())
+    for e in extra:
+        h.update(str(e).encode() + b"\0")
+    return h.hexdigest()
+
+
+def _stale(target, stamp, digest):
+    """An object is reused only if it exists AND was compiled from exactly these bytes with exactly this command (its .sha
+    stamp): modification times say nothing on a box that received the tree by copy."""
+    if not (os.path.exists(target) and os.path.exists(stamp)):
         return True
-    t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(stamp) as f:
+        return f.read().strip() != digest
 
 
 def build(force=False, verbose=True, defines=(), lib=None):
-    """defines/lib: build an experiment variant (-D flags) into another .so without touching the shipped one."""
+    """defines/lib: build an experiment variant (-D flags) into another .so without touching the shipped one.
+    Returns the library path; `build.last_compiled` lists the sources this call actually compiled."""
     hipcc = _hipcc()
     tag = "" if not defines else "_" + "_".join(d.replace("=", "") for d in defines)
     objdir = os.path.join(HERE, "build" + tag)
     out = lib or LIB                                   # (a variant's path must not stick to later default builds)
     os.makedirs(objdir, exist_ok=True)
     headers = [os.path.join(CSRC, h) for h in ("common.h", "conv_common.h", "conv_f16s.h", "conv_f16s_ws.h")] + [
-        os.path.join(HERE, "..", "include", "msnet_hip.h"), os.path.abspath(__file__)]
-    objs = []
-    procs = []
+        os.path.join(HERE, "..", "include", "msnet_hip.h")]
+    objs, procs, stamps = [], [], {}
     for src, extra in SOURCES:
         sp = os.path.join(CSRC, src)
         op = os.path.join(objdir, src + ".o")
         objs.append(op)
-        if force or _stale(op, [sp] + headers):
-            cmd = [hipcc, "-x", "hip"] + COMMON + extra + ["-D" + d for d in defines] + ["-c", sp, "-o", op]
+        cmd = [hipcc, "-x", "hip"] + COMMON + extra + ["-D" + d for d in defines] + ["-c", sp, "-o", op]
+        digest = _digest([sp] + headers, cmd[1:-1])     # (not the compiler's path, not the output path)
+        if force or _stale(op, op + ".sha", digest):
+            if os.path.exists(op + ".sha"):
+                os.remove(op + ".sha")
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
+            stamps[src] = (op + ".sha", digest)
     failed = [s for s, p in procs if p.wait() != 0]
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
-    if force or procs or _stale(out, objs):
+    for src, (stamp, digest) in stamps.items():
+        with open(stamp, "w") as f:
+            f.write(digest + "\n")
+    link_digest = _digest(objs, [ARCH])
+    if force or procs or _stale(out, out + ".sha", link_digest):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", out] + objs
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(out + ".sha", "w") as f:
+            f.write(link_digest + "\n")
+    build.last_compiled = [s for s, _ in procs]
+    if verbose:
+        print("[build] %s: compiled %d of %d sources (%s), objects keyed by content sha256" % (
+            os.path.basename(out), len(procs), len(SOURCES), "forced" if force else "stale or missing"), flush=True)
     return out
+
+
+build.last_compiled = []
 
 
 if __name__ == "__main__":
