@@ -41,8 +41,8 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)", 
 FP16_MATRIX_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md "HBM3E peak BW" (spec); 6290 measured there with a float4 copy
 SPLIT_MFMAS_PER_PRODUCT = 3         # split-fp16: ah*wh, al*wh, ah*wl  
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
-FACTS_FILE = os.path.join(ROOT, "profiles", "r04_profile_facts.json")     # tools/tools_profile_facts.py (rocprofv3 summaries)
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+FACTS_FILE = os.path.join(ROOT, "profiles", "r05_profile_facts.json")     # tools/tools_profile_facts.py (rocprofv3 summaries)
 WORKLOADS = {
     # name: (padded H, W, maxdisp, description)
     "cfg2": (544, 960, 192, "MS-GCNet forward (MS volume build + 19-conv aggregator + soft-argmin), Scene-Flow "
@@ -161,7 +161,7 @@ def pmc_traffic(key, workload, batch):
 
 
 def profile_facts(workload, batch):
-    """Numbers of the committed rocprofv3 passes (profiles/r04_profile_facts.json: average kernel durations of the
+    """Numbers of the committed rocprofv3 passes (profiles/r05_profile_facts.json: average kernel durations of the
     --kernel-trace --stats run and the clock the chip held under the dominant kernel from the SQ/GRBM counter pass), returned
     only when they were taken on this workload, this batch size and THIS kernel source -- so the live line and the tracked
     profile cannot drift apart unnoticed.  Otherwise None."""
