@@ -236,6 +236,15 @@ int msnet_softargmin(const float* logits, float* disp, int N, int D, int H, int 
  * logits = wscale * deconv(x, w) + bias: wscale undoes a power-of-two pre-scale of w (see msnet_conv3d_k3_cout1); 1 for plain weights. */
 int msnet_deconv5_softargmin(const float* x, const float* w, float bias_host, float wscale, float* disp, int N, int D,
                              int H, int W, int Ci, msnet_stream_t stream);
+/* The same tail with a caller-owned workspace (msnet_deconv5_softargmin_workspace_bytes(N, D, H, W) bytes; 0 = not needed): a
+ * tile's D slices are then cut into depth segments, one workgroup each, whose online-softmax states (max, sum e, sum d*e per
+ * output pixel) meet in a small merge pass -- at the benchmark shapes the single chain per tile leaves the CUs 2.4 workgroups
+ * each and is latency-bound.  The segmentation depends on (D, H, W) only, never on N, so a batch returns its samples' single-
+ * forward bits.  Same logits, same order of pushes inside a segment; against the plain entry the result differs by the
+ * rounding of where the segments' fp32 sums are joined (parity tests hold both against the oracle at the same tolerance). */
+size_t msnet_deconv5_softargmin_workspace_bytes(int N, int D, int H, int W);
+int msnet_deconv5_softargmin_ws(const float* x, const float* w, float bias_host, float wscale, float* disp, int N, int D,
+                                int H, int W, int Ci, void* workspace, size_t workspace_bytes, msnet_stream_t stream);
 /* Un-fused deconv5 (stride 2 or the is_quarter_input_size stride-4/op-3 variant, gcnet_3dcnn.py:88-92).
  * logits: f32[N][s*D][s*H][s*W]. */
 int msnet_deconv3d_cout1(const float* x, const float* w, float bias_host, float* logits, int N, int D,

@@ -73,6 +73,8 @@ SIGNATURES = {
     "msnet_conv3d_k3_cout1": (c_int, [P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_softargmin": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "msnet_deconv5_softargmin": (c_int, [P, P, c_float, c_float, P, c_int, c_int, c_int, c_int, c_int, P]),
+    "msnet_deconv5_softargmin_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "msnet_deconv5_softargmin_ws": (c_int, [P, P, c_float, c_float, P, c_int, c_int, c_int, c_int, c_int, P, c_size_t, P]),
     "msnet_deconv3d_cout1": (c_int, [P, P, c_float, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_trilinear_softargmin": (c_int, [P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_epe_badx": (c_int, [P, P, c_size_t, c_float, c_float, P, P]),

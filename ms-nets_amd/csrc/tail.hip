@@ -7,6 +7,8 @@
 //   msnet_trilinear_softargmin: psmnet_3dcnn.py:167-174 (F.interpolate trilinear align_corners + softmax + sum)
 //   msnet_softargmin          : gcnet_3dcnn.py:126-141 on an explicit logit volume
 //   msnet_deconv3d_cout1      : gcnet_3dcnn.py:88-92 un-fused (stride 2, or stride 4 / output_padding 3)
+#include <stdlib.h>
+
 #include "common.h"
 
 #ifndef TAIL_MINB
@@ -220,9 +222,17 @@ __global__ __launch_bounds__(RT * 32) void deconv5_tail_kernel(const float* __re
 // A workgroup owns 8 x 32 input voxels per slice (8 M-blocks, two per wave) and finishes the 7 x 31 columns whose
 // neighbours (h+1, w+1) are inside it; tiles overlap by one row / column (18 % extra MFMA work, no halo exchange).
 // ---------------------------------------------------------------------------------------------
+// Depth segments (round 5).  The 624 tiles of a 272x480 half-res plane put 2.4 of these workgroups on a CU, each a serial chain
+// of D slice steps whose HBM request has only the step's gather to land in: latency-bound at 4.0 TB/s.  With nseg > 1 a tile's
+// D slices are cut into nseg runs of dseg, one workgroup each (1872 workgroups at nseg = 3: every CU holds its four); a run that
+// does not start at slice 0 first takes slice p0 - 1 through the MFMA / gather phase for its kd = 2 partial only (the carry into
+// logit 2 p0 - 1, no softmax push), and every run leaves its online-softmax state (m, s, t) in `part` [N][nseg][3][2H][2W] for
+// softargmin_merge_kernel instead of a disparity.  Same logits, same pushes in the same order inside a run; only the order in
+// which the runs' sums meet differs from the single chain (another rounding of the same fp32 sums).
 __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                 float bias, float wsc, float* __restrict__ out, int N, int D, int H,
-                                                                int W, int nth, int ntw) {
+                                                                int W, int nth, int ntw, int nseg, int dseg,
+                                                                float* __restrict__ part) {
     constexpr int CI = 32, TH = 8, TW = 32, UH = 7, UW = 31, PS = CI + 4, TS = 33, NT = 256;
     // the tap partials reuse the slice buffer (its fragments are in registers by then): 37 KB per workgroup, so the
     // register file, not LDS, sets the occupancy (three workgroups per CU instead of two: 0.60 -> 0.53 ms)
@@ -231,8 +241,13 @@ __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const
     SliceStage<CI, TH, TW, NT> stg;
     unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tw = bid % ntw; bid /= ntw;
-    const int th = bid % nth;
-    const int n = bid / nth;
+    const int th = bid % nth; bid /= nth;
+    const int seg = bid % nseg;
+    const int n = bid / nseg;
+    const int p0 = seg * dseg;                          // this run: slices [p0, p1); it owns logits 2 p0 - 1 .. 2 p1 - 2 (the last run also 2 D - 1)
+    const int p1 = min(D, p0 + dseg);
+    const int pstart = p0 > 0 ? p0 - 1 : 0;             // (slice p0 - 1: carry only)
+    const int pend = p1 == D ? D : p1 - 1;              // the last run has the closing step P = D (logit 2 D - 1 from the carry alone)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int j = lane & 31, kq = lane >> 5;
     const int h0 = th * UH, w0 = tw * UW;
@@ -266,8 +281,8 @@ __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const
     for (int q = 0; q < 4; ++q) sa[q].init();
     float carry[4] = {0.f, 0.f, 0.f, 0.f};
 
-    stg.load(x, (size_t)n * D * H * W, H, W, h0, w0, tid, true);
-    for (int P = 0; P <= D; ++P) {
+    stg.load(x, ((size_t)n * D + pstart) * H * W, H, W, h0, w0, tid, true);
+    for (int P = pstart; P <= pend; ++P) {
         float p[3][4];
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd)
@@ -278,7 +293,7 @@ __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const
             stg.store(xs, tid);
             __syncthreads();
 #ifdef TAIL_FP32_MFMA
-            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0, w0, tid, P + 1 < D);   // in flight during the MFMAs
+            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0, w0, tid, P + 1 < D && P < pend);   // in flight during the MFMAs
 #endif
 #ifdef TAIL_FP32_MFMA
             f32x4 b[2][4];
@@ -330,7 +345,7 @@ __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const
             }
             // the next slice is requested only now: its 32 registers would otherwise sit under the MFMA phase and cost the third
             // resident workgroup; the gather, the softmax and the other workgroups' phases cover the latency
-            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0, w0, tid, P + 1 < D);
+            stg.load(x, ((size_t)n * D + P + 1) * H * W, H, W, h0, w0, tid, P + 1 < D && P < pend);
 #endif
 #ifdef TAIL_FP32_MFMA
 #pragma unroll
@@ -362,18 +377,50 @@ __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const float lo = (carry[q] + p[0][q]) * wsc + bias, hi = p[1][q] * wsc + bias;
-            if (P >= 1 && P < D) sa[q].push2(lo, (float)(2 * P - 1), hi, (float)(2 * P));
-            else if (P < D)      sa[q].push(hi, (float)(2 * P));
-            else                 sa[q].push(lo, (float)(2 * P - 1));
+            if (P >= p0) {                              // (P = p0 - 1: the previous run's slice, here for its carry only)
+                if (P >= 1 && P < D) sa[q].push2(lo, (float)(2 * P - 1), hi, (float)(2 * P));
+                else if (P < D)      sa[q].push(hi, (float)(2 * P));
+                else                 sa[q].push(lo, (float)(2 * P - 1));
+            }
             carry[q] = p[2][q];
         }
     }
     if (live) {
+        if (nseg == 1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
-            out[((size_t)n * OH + (2 * h + (q >> 1))) * OW + (2 * wq + (q & 1))] = sa[q].result();
+            for (int q = 0; q < 4; ++q)
+                out[((size_t)n * OH + (2 * h + (q >> 1))) * OW + (2 * wq + (q & 1))] = sa[q].result();
+        } else {
+            const size_t plane = (size_t)OH * OW;
+            float* pp = part + ((size_t)n * nseg + seg) * 3 * plane;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const size_t o = (size_t)(2 * h + (q >> 1)) * OW + (2 * wq + (q & 1));
+                pp[o] = sa[q].m; pp[plane + o] = sa[q].s; pp[2 * plane + o] = sa[q].t;
+            }
+        }
     }
 }
+
+// disparity = sum_d d p_d from the nseg online-softmax states of a pixel (deconv5_tail_mfma_kernel with depth segments):
+// m = max m_i, s = sum s_i e^(m_i - m), t = sum t_i e^(m_i - m), in run order.
+__global__ __launch_bounds__(256) void softargmin_merge_kernel(const float* __restrict__ part, float* __restrict__ out, int nseg,
+                                                               size_t plane) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int n = blockIdx.y;
+    if (i >= plane) return;
+    const float* pp = part + (size_t)n * nseg * 3 * plane + i;
+    float m = -INFINITY;
+    for (int k = 0; k < nseg; ++k) m = fmaxf(m, pp[(size_t)k * 3 * plane]);
+    float s = 0.f, t = 0.f;
+    for (int k = 0; k < nseg; ++k) {
+        const float a = expf(pp[(size_t)k * 3 * plane] - m);
+        s += pp[((size_t)k * 3 + 1) * plane] * a;
+        t += pp[((size_t)k * 3 + 2) * plane] * a;
+    }
+    out[(size_t)n * plane + i] = t / s;
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // Conv3d(CI -> 1, k3, p1) head, streamed slice by slice: out[o] = sum_k x[o+k-1] w[k], so input slice P
@@ -648,8 +695,25 @@ extern "C" int msnet_softargmin(const float* logits, float* disp, int N, int D, 
     return check_launch("msnet_softargmin");
 }
 
-extern "C" int msnet_deconv5_softargmin(const float* x, const float* w, float bias, float wscale, float* disp, int N, int D, int H,
-                                        int W, int Ci, msnet_stream_t stream) {
+// Depth segments of the fused tail for ONE sample's tile count (never the batch's: a batch of N must return N single forwards'
+// bits): enough runs that every CU holds its four workgroups about twice over, at least 16 slices each.  1: the single chain.
+static int num_cus_tail();
+static int tail_segments(int D, int H, int W) {
+    if (const char* e = getenv("MSNET_TAIL_SEGS")) {        // test hook: this many runs (clamped to D)
+        const int v = atoi(e);
+        if (v >= 1) return v < D ? v : D;
+    }
+    const long tiles = (long)cdiv(H, 7) * cdiv(W, 31);
+    const long slots = 4L * num_cus_tail();
+    // round(2.4 x slots / tiles): measured in the network at 272x480 (624 tiles, 1024 slots), tail + merge pass, one box
+    // (profiles/r05_tail_segments.txt): 1 run 0.393 ms, 2: 0.367, 3: 0.363, 4: 0.355, 6: 0.374
+    long nseg = (24 * slots + 5 * tiles) / (10 * tiles);
+    if (nseg > D / 16) nseg = D / 16;
+    return nseg < 1 ? 1 : (int)nseg;
+}
+
+static int deconv5_softargmin_impl(const float* x, const float* w, float bias, float wscale, float* disp, int N, int D, int H, int W,
+                                   int Ci, void* workspace, size_t workspace_bytes, msnet_stream_t stream) {
     if (!x || !w || !disp) return fail("msnet_deconv5_softargmin: null pointer");
     if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_deconv5_softargmin: empty input");
     if (Ci != 32) return fail("msnet_deconv5_softargmin: Ci=%d (only 32 is built)", Ci);
@@ -660,13 +724,41 @@ extern "C" int msnet_deconv5_softargmin(const float* x, const float* w, float bi
     hipStream_t s = (hipStream_t)stream;
     const double vox = (double)N * D * H * W;
     LaunchScope ls("deconv5_softargmin", s, 2.0 * 27 * Ci * vox, 4.0 * (vox * Ci + 4.0 * N * H * W));
-    if (valu)
+    if (valu) {
         hipLaunchKernelGGL((deconv5_tail_kernel<32, false, RT, CPT>), dim3((unsigned)(N * nth * ntw)), dim3(RT * 32), 0, s, x, w,
                            bias, wscale, disp, N, D, H, W, nth, ntw);
-    else
-        hipLaunchKernelGGL(deconv5_tail_mfma_kernel, dim3((unsigned)(N * nth * ntw)), dim3(256), 0, s, x, w, bias, wscale, disp, N, D, H, W,
-                           nth, ntw);
+        return check_launch("msnet_deconv5_softargmin");
+    }
+    int nseg = workspace ? tail_segments(D, H, W) : 1;
+    int dseg = cdiv(D, nseg);
+    nseg = cdiv(D, dseg);                                  // (no empty run)
+    const size_t plane = (size_t)4 * H * W;
+    if (nseg > 1 && workspace_bytes < (size_t)N * nseg * 3 * plane * sizeof(float)) { nseg = 1; dseg = D; }    // too small a workspace: the single chain
+    if ((size_t)N * nseg * nth * ntw > 0x7fffffffu) return fail("msnet_deconv5_softargmin: too many tiles");
+    hipLaunchKernelGGL(deconv5_tail_mfma_kernel, dim3((unsigned)(N * nseg * nth * ntw)), dim3(256), 0, s, x, w, bias, wscale, disp, N, D,
+                       H, W, nth, ntw, nseg, dseg, (float*)workspace);
+    if (nseg > 1)
+        hipLaunchKernelGGL(softargmin_merge_kernel, dim3((unsigned)((plane + 255) / 256), (unsigned)N), dim3(256), 0, s,
+                           (const float*)workspace, disp, nseg, plane);
     return check_launch("msnet_deconv5_softargmin");
+}
+
+extern "C" int msnet_deconv5_softargmin(const float* x, const float* w, float bias, float wscale, float* disp, int N, int D, int H,
+                                        int W, int Ci, msnet_stream_t stream) {
+    return deconv5_softargmin_impl(x, w, bias, wscale, disp, N, D, H, W, Ci, nullptr, 0, stream);
+}
+
+// bytes of the depth-segmented form's partial softmax states (0: this shape runs the single chain)
+extern "C" size_t msnet_deconv5_softargmin_workspace_bytes(int N, int D, int H, int W) {
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    int nseg = tail_segments(D, H, W);
+    nseg = cdiv(D, cdiv(D, nseg));
+    return nseg > 1 ? (size_t)N * nseg * 3 * 4 * H * W * sizeof(float) : 0;
+}
+
+extern "C" int msnet_deconv5_softargmin_ws(const float* x, const float* w, float bias, float wscale, float* disp, int N, int D, int H,
+                                           int W, int Ci, void* workspace, size_t workspace_bytes, msnet_stream_t stream) {
+    return deconv5_softargmin_impl(x, w, bias, wscale, disp, N, D, H, W, Ci, workspace, workspace_bytes, stream);
 }
 
 extern "C" int msnet_deconv3d_cout1(const float* x, const float* w, float bias, float* logits, int N, int D, int H,

@@ -395,8 +395,15 @@ def deconv5_softargmin(x, w, bias, wscale=1.0):
     w = require_gpu_f32(w, "weight")
     n, d, h, wd, ci = x.shape
     disp = torch.empty((n, 2 * h, 2 * wd), device=x.device, dtype=torch.float32)
-    check(_lib.load().msnet_deconv5_softargmin(ptr(x), ptr(w), float(bias), float(wscale), ptr(disp), n, d, h, wd, ci, stream_ptr()),
-          "msnet_deconv5_softargmin")
+    lib = _lib.load()
+    nbytes = int(lib.msnet_deconv5_softargmin_workspace_bytes(n, d, h, wd))
+    if nbytes:                            # depth-segmented tail: partial softmax states of the segments (arena memory)
+        ws = _new(((nbytes + 3) // 4,), x.device)
+        check(lib.msnet_deconv5_softargmin_ws(ptr(x), ptr(w), float(bias), float(wscale), ptr(disp), n, d, h, wd, ci, ptr(ws), nbytes,
+                                              stream_ptr()), "msnet_deconv5_softargmin_ws")
+    else:
+        check(lib.msnet_deconv5_softargmin(ptr(x), ptr(w), float(bias), float(wscale), ptr(disp), n, d, h, wd, ci, stream_ptr()),
+              "msnet_deconv5_softargmin")
     return disp
 
 

@@ -40,6 +40,9 @@ FULL_CASES = {
     # through trunk channel 0 into deconv5 with gain `unimodal`
     "gcnet_cfg2_ms_unimodal": dict(model="gcnet", seed=46, maxdisp=192, in_shape=(1, 8, 96, 272, 480), ms_volume=True,
                                    unimodal=6.0),
+    # round 5: BASELINE.json configs[0] -- one synthetic 256x512 pair, D = 64 -- end to end: the MS volume of the pair into the
+    # reference aggregator (random-init, randomised BN), and on the GPU from the two images through the HIP volume build
+    "gcnet_cfg1_ms": dict(model="gcnet", seed=51, maxdisp=64, in_shape=(1, 8, 32, 128, 256), ms_volume=True),
 }
 # Cases whose flat-1e-3 gate is exceeded on part of the map also carry the reference's OWN fp32 noise floor:
 # tests/golden/fullsize_<case>_alt.npz = the unmodified reference forward, same weights, same input, under other CPU thread

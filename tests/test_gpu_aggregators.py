@@ -410,6 +410,38 @@ def test_deconv5_logits_and_fused_tail(gpu, dims, stride):
         assert float((fused.cpu() - ref_disp).abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("dims,gain", [((1, 20, 9, 40), 0.2), ((2, 32, 16, 33), 0.2), ((1, 48, 7, 31), 3.0), ((1, 5, 8, 8), 0.2)])
+def test_fused_tail_depth_segments(gpu, monkeypatch, dims, gain):
+    """msnet_deconv5_softargmin_ws cuts a tile's D slices into depth segments whose online-softmax states meet in a merge pass.
+    Every segment count -- 1 (the single chain), ragged (20 slices in 3 runs of 7, 7, 6), one slice per run -- must give the
+    oracle's disparity at the tolerance of the single chain, broad and peaky softmax alike; the segment boundary (the carry of
+    slice p0 - 1 into logit 2 p0 - 1) is where an off-by-one would show.  And the count depends on the sample's shape only: a
+    batch returns the bits of its samples' single forwards."""
+    from msnets_amd import hipops
+    g = torch.Generator().manual_seed(19)
+    n, d, h, w = dims
+    x = torch.randn((n, 32, d, h, w), generator=g)
+    wt = torch.randn((32, 1, 3, 3, 3), generator=g) * gain
+    bias = -0.21
+    ref = oracle.soft_argmin(F.conv_transpose3d(x, wt, torch.tensor([bias]), stride=2, padding=1, output_padding=1).squeeze(1))
+    xcl, wg = _cl(x), wt.cuda()
+    outs = {}
+    for segs in (1, 2, 3, 4, d):
+        monkeypatch.setenv("MSNET_TAIL_SEGS", str(segs))
+        outs[segs] = hipops.deconv5_softargmin(xcl, wg, bias).cpu()
+        err = float((outs[segs] - ref).abs().max())
+        print("tail segments %d (D'=%d): max |disp - oracle| %.2e" % (segs, d, err))
+        assert err < (1e-4 if gain < 1 else 5e-4), (segs, err)
+    assert float((outs[3] - outs[1]).abs().max()) < (2e-5 if gain < 1 else 2e-4)
+    monkeypatch.setenv("MSNET_TAIL_SEGS", "3")
+    if n > 1:
+        for i in range(n):
+            assert torch.equal(hipops.deconv5_softargmin(xcl[i:i + 1].contiguous(), wg, bias).cpu()[0], outs[3][i])
+    monkeypatch.delenv("MSNET_TAIL_SEGS")
+    auto = hipops.deconv5_softargmin(xcl, wg, bias).cpu()          # the library's own choice for this shape
+    assert float((auto - ref).abs().max()) < (1e-4 if gain < 1 else 5e-4)
+
+
 def test_softargmin_peaky_and_flat(gpu):
     from msnets_amd import hipops
     g = torch.Generator().manual_seed(3)

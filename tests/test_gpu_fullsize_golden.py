@@ -46,7 +46,7 @@ KAPPA_FLAT = 1.0        # pixels at least this well conditioned must meet the fl
 NOISE_FACTOR = {"HIP split-fp16": {"p99": 1.25, "p99.9": 1.25, "max": 1.5, "beyond": 1.5},
                 "HIP exact fp32": {"p99": 2.0, "p99.9": 2.0, "max": 2.5, "beyond": 4.0}}
 # fraction of the map within a flat 1e-3: the value measured in round 3 (profiles/r03x_parity_errors.txt) minus half a point
-FRAC_FLAT_MIN = {"gcnet_cfg2": 0.995, "gcnet_cfg5": 0.995, "gcnet_cfg2_ms_unimodal": 0.995, "gcnet_cfg2_peaky": 0.9897,
+FRAC_FLAT_MIN = {"gcnet_cfg1_ms": 0.995, "gcnet_cfg2": 0.995, "gcnet_cfg5": 0.995, "gcnet_cfg2_ms_unimodal": 0.995, "gcnet_cfg2_peaky": 0.9897,
                  "gcnet_cfg2_ms_peaky": 0.9946, "gcnet_cfg5_peaky": 0.9936, "psmnet_cfg3": 0.9918, "psmnet_cfg3_peaky": 0.9743}
 
 
