@@ -22,7 +22,14 @@ Rank 0 prints ONE JSON line (contract in the task statement) extended with
   power           : package power over the timed region (the SMU's energy counter) and the granted shader clock (per-XCD probe);
   step_ms         : median / p10 / p90 of the K per-step times (HIP events between the steps of the timed region);
   fp32_exact      : the same step timed again with every conv on the exact fp32-input MFMA (the reference's arithmetic);
-  cpu_baseline    : the CPU oracle (a port, not the reference binary) timed on this host on a bounded sample.
+  dropin_ncdhw    : the same step through the REFERENCE's module contract -- VolumeBuilder(layout="ncdhw") + forward(cv[N,8,D',H',W'])
+                    (gcnet_3dcnn.py:97) -- timed behind the fp32 loop, same bits as the headline route (`max_abs_diff_vs_headline_route`
+                    = 0); `value` itself times the channels-last hand-over (forward_ndhwc) unless --volume-layout ncdhw.  Compare the
+                    two routes with interleaved runs of the two flags, not within one line (DESIGN.md section 7);
+  cpu_baseline    : the CPU oracle (a port, not the reference binary) timed on this host on a bounded sample: `value`, and
+                    `volume_s` / `aggregator_s` as numbers;
+  config.per_rank : one row per rank (device, PCI bus id, NUMA node bound, pairs per step, local ms per step), gathered through the
+                    process group; config.weights says how the timed weights were drawn (seeded net_init + randomised BatchNorm).
 """
 import argparse
 import hashlib

@@ -404,6 +404,10 @@ __global__ __launch_bounds__(256, TAIL_MINB) void deconv5_tail_mfma_kernel(const
 
 // disparity = sum_d d p_d from the nseg online-softmax states of a pixel (deconv5_tail_mfma_kernel with depth segments):
 // m = max m_i, s = sum s_i e^(m_i - m), t = sum t_i e^(m_i - m), in run order.
+// (Measured and not kept: pushing disparities RELATIVE to the run's first one, so that sum (d - c) e carries the rounding of a
+// number below 2 dseg instead of 2 D -- closer to the exact value in a CPU emulation, but |HIP - reference| on the full-size
+// unimodal case went 3.05e-4 -> 3.20e-4: what separates the fused tail from the reference there is the reference's own fp32
+// tail, which no amount of accuracy on this side removes.)
 __global__ __launch_bounds__(256) void softargmin_merge_kernel(const float* __restrict__ part, float* __restrict__ out, int nseg,
                                                                size_t plane) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -420,7 +424,6 @@ __global__ __launch_bounds__(256) void softargmin_merge_kernel(const float* __re
     }
     out[(size_t)n * plane + i] = t / s;
 }
-
 
 // ---------------------------------------------------------------------------------------------
 // Conv3d(CI -> 1, k3, p1) head, streamed slice by slice: out[o] = sum_k x[o+k-1] w[k], so input slice P

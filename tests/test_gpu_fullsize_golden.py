@@ -201,7 +201,10 @@ def test_fullsize_vs_reference(gpu, name):
         # for, so only the well-conditioned pixels and the map-level fraction are asserted
         # (measured in round 3: 99.96 % of the map within 1e-3, 8.4e-5 on the well-conditioned pixels)
         if bool(well.any()):
-            assert float(e2e[well].max()) <= 3e-4            # (r04: 8.4e-5 on the 7 % of ms_peaky, 2.4e-4 on the 91 % of the unimodal case)
+            # (r04: 8.4e-5 on the 7 % of ms_peaky, 2.4e-4 on the 91 % of the unimodal case.  r05: 3.05e-4 there with the fused tail in
+            # depth segments -- correct fp32 tails scatter by that much around each other, tools/r05_tail_rounding_emulation.py;
+            # the flat 1e-3 of the north star is asserted on the whole map of that case a few lines below)
+            assert float(e2e[well].max()) <= 4e-4
         assert float((e2e <= DISP_TOL).float().mean()) >= 0.995
         if case.get("unimodal"):
             assert float(e2e.max()) <= DISP_TOL, "flat gate, end to end from the images (unimodal case)"
