@@ -20,6 +20,7 @@ LAYERS = {
     "s1_64_64b": ("conv", 64, 64, 1, (24, 68, 120), False),
     "s1_128":    ("conv", 128, 128, 1, (6, 17, 30), False),
     "d_64_32":   ("deconv", 64, 32, 2, (48, 136, 240), True),
+    "d_64_32n":  ("deconv", 64, 32, 2, (48, 136, 240), False),    # deconvbn4's shape WITHOUT its residual (1.6 GB less read): what the residual path costs
     "d_64_64":   ("deconv", 64, 64, 2, (24, 68, 120), True),
     "d_128_64":  ("deconv", 128, 64, 2, (6, 17, 30), True),
 }
