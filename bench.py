@@ -98,7 +98,10 @@ class PowerMeter:
     def __init__(self, index, dev):
         import ctypes
         self.ct, self.index, self.rsmi, self.e0, self.t0 = ctypes, index, None, None, None
-        for cand in ("/opt/rocm/lib/librocm_smi64.so", "librocm_smi64.so"):
+        # rocm_smi numbers the node's devices; HIP numbers the VISIBLE ones.  Under any visible-device remapping `index` would name
+        # another GPU's energy counter: no power figure then (the clock probe runs on the device itself and stays).
+        remapped = any(os.environ.get(k) for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"))
+        for cand in (() if remapped else ("/opt/rocm/lib/librocm_smi64.so", "librocm_smi64.so")):
             try:
                 lib = ctypes.CDLL(cand)
                 if lib.rsmi_init(0) == 0:
