@@ -100,7 +100,8 @@ class PowerMeter:
         self.ct, self.index, self.rsmi, self.e0, self.t0 = ctypes, index, None, None, None
         # rocm_smi numbers the node's devices; HIP numbers the VISIBLE ones.  Under any visible-device remapping `index` would name
         # another GPU's energy counter: no power figure then (the clock probe runs on the device itself and stays).
-        remapped = any(os.environ.get(k) for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"))
+        from msnets_amd import dist as _msdist
+        remapped = _msdist.devices_remapped()              # ("0" / "0,1,..." re-number nothing: this pool exports ROCR_VISIBLE_DEVICES=0)
         for cand in (() if remapped else ("/opt/rocm/lib/librocm_smi64.so", "librocm_smi64.so")):
             try:
                 lib = ctypes.CDLL(cand)

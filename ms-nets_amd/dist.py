@@ -44,6 +44,18 @@ def _gpu_cards():
     return out
 
 
+def devices_remapped(env=None):
+    """True if ROCR_/HIP_/CUDA_VISIBLE_DEVICES or GPU_DEVICE_ORDINAL re-number the node's GPUs, i.e. HIP ordinal i may not be the
+    node's device i (sysfs card order, rocm_smi index).  A variable that lists the identity prefix "0,1,...,k-1" (what a
+    one-GPU-per-container pool exports: "0") hides devices but re-numbers none."""
+    env = os.environ if env is None else env
+    for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL"):
+        v = env.get(k)
+        if v and [t.strip() for t in v.split(",")] != [str(i) for i in range(len(v.split(",")))]:
+            return True
+    return False
+
+
 def _parse_cpulist(text):
     cpus = set()
     for part in text.strip().split(","):
@@ -61,8 +73,8 @@ def bind_to_gpu_numa_node(local_rank):
     node bound to, or None (single-node host, no such file, visible-device remapping that cannot be resolved: nothing done)."""
     try:
         cards = _gpu_cards()
-        # any visible-device remapping (the three variables compose) makes "HIP ordinal -> drm card" a guess: do nothing then
-        if any(os.environ.get(k) for k in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_DEVICE_ORDINAL")):
+        # a visible-device REMAPPING (the variables compose) makes "HIP ordinal -> drm card" a guess: do nothing then
+        if devices_remapped():
             return None
         if not cards or local_rank >= len(cards):
             return None

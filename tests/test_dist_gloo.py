@@ -81,3 +81,13 @@ def test_oversubscription_rule_per_launcher_env():
         assert oversubscribed({"WORLD_SIZE": "32", "RANK": str(8 + lr), "LOCAL_RANK": str(lr)}, lr, 8)[0] is False
     # the same launcher with more local ranks than devices is still caught, by the rank that has no device
     assert oversubscribed({"WORLD_SIZE": "32"}, 8, 8)[0] is True
+
+
+def test_devices_remapped_rule():
+    from msnets_amd.dist import devices_remapped
+    assert devices_remapped({}) is False
+    assert devices_remapped({"ROCR_VISIBLE_DEVICES": "0", "HIP_VISIBLE_DEVICES": "0"}) is False       # this pool's boxes
+    assert devices_remapped({"HIP_VISIBLE_DEVICES": "0,1,2,3"}) is False
+    assert devices_remapped({"HIP_VISIBLE_DEVICES": "3"}) is True
+    assert devices_remapped({"ROCR_VISIBLE_DEVICES": "1,0"}) is True
+    assert devices_remapped({"CUDA_VISIBLE_DEVICES": "GPU-deadbeef"}) is True
