@@ -55,19 +55,29 @@ static bool prof_selected(const char* n) {
     return false;
 }
 
-LaunchScope::LaunchScope(const char* n, hipStream_t s, double flops, double bytes) : name(n), stream(s), rec(nullptr) {
+LaunchScope::LaunchScope(const char* n, hipStream_t s, double flops, double bytes, bool attach_)
+    : name(n), stream(s), rec(nullptr), attach(attach_) {
     if (!g_prof) return;
     if (!prof_selected(n)) return;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;      // a launch being captured into a graph is not timed (its events
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return;      // would belong to the capture)
     Rec* r = new Rec{n, nullptr, nullptr, flops, bytes};
     if (hipEventCreate(&r->a) != hipSuccess || hipEventCreate(&r->b) != hipSuccess) { delete r; return; }
-    (void)hipEventRecord(r->a, s);
+    if (!attach) (void)hipEventRecord(r->a, s);
     rec = r;
+}
+
+bool LaunchScope::events(hipEvent_t* start, hipEvent_t* stop) const {
+    if (!rec || !attach) return false;
+    Rec* r = static_cast<Rec*>(rec);
+    *start = r->a; *stop = r->b;
+    return true;
 }
 
 LaunchScope::~LaunchScope() {
     if (!rec) return;
     Rec* r = static_cast<Rec*>(rec);
-    (void)hipEventRecord(r->b, stream);
+    if (!attach) (void)hipEventRecord(r->b, stream);
     std::lock_guard<std::mutex> lk(g_mu);
     g_recs.push_back(r);
 }

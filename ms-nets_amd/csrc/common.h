@@ -1,6 +1,7 @@
 // Shared host-side plumbing for libmsnet_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -24,10 +25,22 @@ int  fail(const char* fmt, ...);   // set_error + return 1
 // Profiling hooks (api.cpp).  Each kernel launch goes through LaunchScope so that, when profiling
 // is enabled, a start/stop hipEvent pair on the launch stream brackets exactly that launch.
 struct LaunchScope {
-    LaunchScope(const char* name, hipStream_t s, double flops, double bytes);
+    // attach = true: the scope brackets exactly ONE kernel, launched through MSNET_LAUNCH below: its start / stop events ride on that
+    // kernel's own dispatch packet (hipExtLaunchKernelGGL) instead of being recorded as two barrier packets around it, so a timed
+    // launch no longer keeps the next kernel from starting under its drain (the ten recorded pairs of a default bench step cost
+    // 1.2 % of the step) and the pair measures the kernel itself, as rocprofv3 does.
+    LaunchScope(const char* name, hipStream_t s, double flops, double bytes, bool attach = false);
     ~LaunchScope();
-    const char* name; hipStream_t stream; void* rec;
+    bool events(hipEvent_t* start, hipEvent_t* stop) const;       // attach mode, profiling on: the pair to hand to the launch
+    const char* name; hipStream_t stream; void* rec; bool attach;
 };
+// one kernel under an attach-mode scope: hipExtLaunchKernelGGL with the scope's events when this launch is being timed
+#define MSNET_LAUNCH(ls, kernel, grid, block, lds, stream, ...)                                                        \
+    do {                                                                                                               \
+        hipEvent_t ea_ = nullptr, eb_ = nullptr;                                                                       \
+        if ((ls).events(&ea_, &eb_)) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, ea_, eb_, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                        \
+    } while (0)
 
 // The likelihood numerator exp(-(c - m)^2 / sigma) (featextract.cpp:444-449) as v_exp_f32((c - m)^2 * k), k = RN(-log2(e) / sigma)
 // formed once per launch in double.  The library route -- IEEE division by sigma (or its three-operation equivalent), then

@@ -227,8 +227,8 @@ static int launch_c8_f16s(const char* name, ConvArgs a, hipStream_t s) {
     const size_t nblk = ntiles < cap ? ntiles : cap;
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
-                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((conv3d_c8_f16s_kernel<NB, NCS, INCHK>), dim3((unsigned)nblk), dim3(256), 0, s, a);
+                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)), true);
+    MSNET_LAUNCH(ls, (conv3d_c8_f16s_kernel<NB, NCS, INCHK>), dim3((unsigned)nblk), dim3(256), 0, s, a);
     return check_launch(name);
 }
 

@@ -358,8 +358,8 @@ static int launch_deconv_f16s(const char* name, ConvArgs a, hipStream_t s) {
         return fail("%s: a sample exceeds the buffer-descriptor range of this kernel (use the fp32 path)", name);
     const size_t nblk = nitems < (size_t)num_cus() ? nitems : (size_t)num_cus();
     const double ivox = (double)a.N * a.D * a.H * a.W;
-    LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * ivox, 4.0 * (ivox * a.Ci + 8.0 * ivox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((deconv3d_k3s2_f16s_ws<KS, NB, DEC_LOADER_WAVES>), dim3((unsigned)nblk), dim3(256 + 64 * DEC_LOADER_WAVES), 0, s, a);
+    LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * ivox, 4.0 * (ivox * a.Ci + 8.0 * ivox * a.Co * (a.res ? 2 : 1)), true);
+    MSNET_LAUNCH(ls, (deconv3d_k3s2_f16s_ws<KS, NB, DEC_LOADER_WAVES>), dim3((unsigned)nblk), dim3(256 + 64 * DEC_LOADER_WAVES), 0, s, a);
     return check_launch(name);
 }
 

@@ -122,11 +122,11 @@ static int launch_direct_f16s(const char* name, ConvArgs a, int stride, int KS, 
     const int KK = a.Ci / 16;
     const double vox = TR ? (double)a.N * a.D * a.H * a.W : (double)total;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
-                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + (double)total * a.Co * (a.res ? 2 : 1)));
+                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + (double)total * a.Co * (a.res ? 2 : 1)), true);
     const dim3 g((unsigned)nblocks), b(256);
-    if (KK == 2)      hipLaunchKernelGGL((conv3d_direct_f16s_kernel<TR, 2>), g, b, 0, s, a, stride, KS, NBG);
-    else if (KK == 4) hipLaunchKernelGGL((conv3d_direct_f16s_kernel<TR, 4>), g, b, 0, s, a, stride, KS, NBG);
-    else              hipLaunchKernelGGL((conv3d_direct_f16s_kernel<TR, 8>), g, b, 0, s, a, stride, KS, NBG);
+    if (KK == 2)      MSNET_LAUNCH(ls, (conv3d_direct_f16s_kernel<TR, 2>), g, b, 0, s, a, stride, KS, NBG);
+    else if (KK == 4) MSNET_LAUNCH(ls, (conv3d_direct_f16s_kernel<TR, 4>), g, b, 0, s, a, stride, KS, NBG);
+    else              MSNET_LAUNCH(ls, (conv3d_direct_f16s_kernel<TR, 8>), g, b, 0, s, a, stride, KS, NBG);
     return check_launch(name);
 }
 

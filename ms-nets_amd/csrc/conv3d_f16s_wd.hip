@@ -384,8 +384,8 @@ static int launch_wd_f16s(const char* name, ConvArgs a, hipStream_t s) {
     const size_t nblk = units < (size_t)num_cus() ? units : (size_t)num_cus();
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     // (a.Ci / a.Co are record strides here; the kernel always contracts 32 x 32 channels)
-    LaunchScope ls(name, s, 2.0 * 27.0 * 32 * 32 * vox, 4.0 * ((double)a.N * a.D * a.H * a.W * 32 + vox * 32 * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL(conv3d_wd_f16s_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
+    LaunchScope ls(name, s, 2.0 * 27.0 * 32 * 32 * vox, 4.0 * ((double)a.N * a.D * a.H * a.W * 32 + vox * 32 * (a.res ? 2 : 1)), true);
+    MSNET_LAUNCH(ls, conv3d_wd_f16s_kernel, dim3((unsigned)nblk), dim3(512), 0, s, a);
     return check_launch(name);
 }
 

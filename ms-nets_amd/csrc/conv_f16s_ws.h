@@ -866,8 +866,8 @@ int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     const size_t nblk = ntiles < (size_t)num_cus() ? ntiles : (size_t)num_cus();
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
-                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB, SWZ, KS, RESB, STRIDE, false, LW>), dim3((unsigned)nblk), dim3(256 + 64 * LW), 0, s, a);
+                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)), true);
+    MSNET_LAUNCH(ls, (conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB, SWZ, KS, RESB, STRIDE, false, LW>), dim3((unsigned)nblk), dim3(256 + 64 * LW), 0, s, a);
     return check_launch(name);
 }
 
@@ -906,8 +906,8 @@ int launch_f16s_slide(const char* name, ConvArgs a, hipStream_t s) {
     const size_t nblk = units < (size_t)num_cus() ? units : (size_t)num_cus();
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
-                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)));
-    hipLaunchKernelGGL((conv3d_k3s1_f16s_ws<TD, TH, TW, 32, MB, NB, false, 2, false, 1, true, SLIDE_LOADER_WAVES>), dim3((unsigned)nblk), dim3(256 + 64 * SLIDE_LOADER_WAVES), 0, s, a);
+                   4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)), true);
+    MSNET_LAUNCH(ls, (conv3d_k3s1_f16s_ws<TD, TH, TW, 32, MB, NB, false, 2, false, 1, true, SLIDE_LOADER_WAVES>), dim3((unsigned)nblk), dim3(256 + 64 * SLIDE_LOADER_WAVES), 0, s, a);
     return check_launch(name);
 }
 
