@@ -801,10 +801,15 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
     const bool overlap = want_overlap && aux.ok && !channels_last;
     hipStream_t sb = overlap ? aux.s : s;                  // stream of the Sobel-SAD kernels
 
-    LaunchScope whole("vol_build", s, 0, 4.0 * 8.0 * nd * (double)plane + 2.0 * img);     // the whole build on the caller's stream
+    // the whole build on the caller's stream: timed from the start of its FIRST kernel to the end of its LAST one, both on the
+    // caller's stream, through events attached to those two kernels' dispatch packets (common.h: no barrier packets in the stream)
+    LaunchScope whole("vol_build", s, 0, 4.0 * 8.0 * nd * (double)plane + 2.0 * img, true);
+    hipEvent_t ev_first = nullptr, ev_last = nullptr;
+    const bool timed = whole.events(&ev_first, &ev_last);
     {
         LaunchScope ls("volk_prep", s, 0, 2.0 * img + 72.0 * img);
-        hipLaunchKernelGGL(vprep_kernel, dim3(cdiv(Wb, 64), cdiv(Hb, 4), 3), dim3(256), 0, s, a);
+        if (timed) hipExtLaunchKernelGGL(vprep_kernel, dim3(cdiv(Wb, 64), cdiv(Hb, 4), 3), dim3(256), 0, s, ev_first, nullptr, 0, a);
+        else hipLaunchKernelGGL(vprep_kernel, dim3(cdiv(Wb, 64), cdiv(Hb, 4), 3), dim3(256), 0, s, a);
     }
     if (overlap) {
         if (hipEventRecord(aux.fork, s) != hipSuccess || hipStreamWaitEvent(aux.s, aux.fork, 0) != hipSuccess)
@@ -843,27 +848,34 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
         if (rc) return rc;
     }
     if (overlap && hipEventRecord(aux.join, aux.s) != hipSuccess) return fail("msnet_build_volume: stream join failed");
-    auto features = [&](int zbase, int nz) {
+    // (last = true: the build's last kernel carries the whole-build stop event)
+    auto features = [&](int zbase, int nz, bool last) {
         const dim3 g(gpix.x, gpix.y, nz);
-        if (nd <= 32) hipLaunchKernelGGL(features4_kernel<32>, g, dim3(256), 0, s, a, zbase);
-        else hipLaunchKernelGGL(features4_kernel<96>, g, dim3(256), 0, s, a, zbase);
+        hipEvent_t stop = (last && timed) ? ev_last : nullptr;
+        if (nd <= 32) { if (stop) hipExtLaunchKernelGGL(features4_kernel<32>, g, dim3(256), 0, s, nullptr, stop, 0, a, zbase);
+                        else hipLaunchKernelGGL(features4_kernel<32>, g, dim3(256), 0, s, a, zbase); }
+        else          { if (stop) hipExtLaunchKernelGGL(features4_kernel<96>, g, dim3(256), 0, s, nullptr, stop, 0, a, zbase);
+                        else hipLaunchKernelGGL(features4_kernel<96>, g, dim3(256), 0, s, a, zbase); }
     };
     if (channels_last) {
         LaunchScope ls("volk_features", s, 0, 4.0 * 8.0 * nd * (double)plane);
         const dim3 g(gpix.x, a.Hc, 1);
-        if (nd <= 32) hipLaunchKernelGGL(features_cl_kernel<32>, g, dim3(256), 0, s, a, park_ws);
-        else hipLaunchKernelGGL(features_cl_kernel<96>, g, dim3(256), 0, s, a, park_ws);
+        hipEvent_t stop = timed ? ev_last : nullptr;
+        if (nd <= 32) { if (stop) hipExtLaunchKernelGGL(features_cl_kernel<32>, g, dim3(256), 0, s, nullptr, stop, 0, a, (const float*)park_ws);
+                        else hipLaunchKernelGGL(features_cl_kernel<32>, g, dim3(256), 0, s, a, park_ws); }
+        else          { if (stop) hipExtLaunchKernelGGL(features_cl_kernel<96>, g, dim3(256), 0, s, nullptr, stop, 0, a, (const float*)park_ws);
+                        else hipLaunchKernelGGL(features_cl_kernel<96>, g, dim3(256), 0, s, a, park_ws); }
     } else if (overlap) {
         {
             LaunchScope ls("volk_features", s, 0, 4.0 * 6.0 * nd * (double)plane);
-            features(0, 3);                                 // ZSAD, NCC, census: no dependence on the Sobel-SAD stream
+            features(0, 3, false);                          // ZSAD, NCC, census: no dependence on the Sobel-SAD stream
         }
         if (hipStreamWaitEvent(s, aux.join, 0) != hipSuccess) return fail("msnet_build_volume: stream join failed");
         LaunchScope ls("volk_features_sobel", s, 0, 4.0 * 2.0 * nd * (double)plane);
-        features(3, 1);
+        features(3, 1, true);
     } else {
         LaunchScope ls("volk_features", s, 0, 4.0 * 8.0 * nd * (double)plane);
-        features(0, 4);
+        features(0, 4, true);
     }
     return check_launch("msnet_build_volume");
 }
