@@ -30,7 +30,7 @@ FAMILIES = {
                                  or "conv3d_direct_f16s_kernel<false, 4>" in n),
     "deconv3d_f16s": lambda n: "deconv3d_k3s2_f16s_ws" in n or "conv3d_direct_f16s_kernel<true" in n,
     "conv3d_s1_c8_f16s": lambda n: "conv3d_c8_f16s_kernel" in n,
-    "deconv5_softargmin": lambda n: "deconv5_tail_mfma_kernel" in n,
+    "deconv5_softargmin": lambda n: "deconv5_tail_mfma_kernel" in n or "softargmin_merge_kernel" in n,
 }
 
 
