@@ -60,3 +60,27 @@ def test_product_path_has_no_cpu_fallback():
         if f.endswith(".py"):
             src += open(os.path.join(pkg, f)).read()
     assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_build_reuses_objects_by_content_not_by_mtime(tmp_path):
+    """ms-nets_amd/build.py keys every object (and the linked library) by the sha256 of the bytes and the command it was made
+    from: touching a source changes nothing, editing it (or a flag) does -- on a box that received the tree by copy, modification
+    times say nothing."""
+    import importlib
+    import os
+    import time
+    build = importlib.import_module("ms-nets_amd.build")
+    src, obj = tmp_path / "k.hip", tmp_path / "k.hip.o"
+    src.write_text("__global__ void k() {}\n")
+    obj.write_bytes(b"\x7fELF")
+    d0 = build._digest([str(src)], ["-O3"])
+    assert build._stale(str(obj), str(obj) + ".sha", d0)                    # no stamp yet
+    (tmp_path / "k.hip.o.sha").write_text(d0 + "\n")
+    assert not build._stale(str(obj), str(obj) + ".sha", d0)
+    os.utime(src, (time.time() + 100, time.time() + 100))                    # newer mtime, same bytes: still fresh
+    assert not build._stale(str(obj), str(obj) + ".sha", build._digest([str(src)], ["-O3"]))
+    assert build._stale(str(obj), str(obj) + ".sha", build._digest([str(src)], ["-O2"]))      # another flag
+    src.write_text("__global__ void k() { }\n")
+    assert build._stale(str(obj), str(obj) + ".sha", build._digest([str(src)], ["-O3"]))      # other bytes
+    # the shipped library carries its own stamp, and the stamp matches the objects it was linked from when they are present
+    assert os.path.exists(build.LIB + ".sha")
