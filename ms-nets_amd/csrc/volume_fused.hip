@@ -361,6 +361,54 @@ __device__ __forceinline__ void stage_right(const FastArgs& a, unsigned char* sm
     }
 }
 
+// ZSAD raw costs of disparities [D0, D1) of one pixel (matchers.cpp:442-512: 25 window terms, fp32, fixed order) into c[D0..D1).
+// A separate function so that a second wave can take the upper half of the range (features_cl_kernel): the sliding 5x5 window
+// starts at any D0, and every c[d] is the same chain of operations whichever wave forms it.
+template <int ND, int TR, int D0, int D1>
+__device__ __forceinline__ void zsad_costs(const FastArgs& a, const unsigned char* smem, int tx, int ty, int xb, int yb, int nd,
+                                           float (&c)[ND]) {
+    constexpr int SW_ = 64 + ND - 1;
+    static_assert(D0 % 8 == 0 && D1 % 8 == 0 && D0 < D1 && D1 <= ND, "disparity range in groups of eight");
+    const int W = a.Wb;
+    const size_t pl = (size_t)yb * W + xb;
+    const float mlv = a.ml[pl];
+    const float* sm = reinterpret_cast<const float*>(smem) + ty * SW_ + tx + (ND - 1);
+    const float* si = reinterpret_cast<const float*>(smem) + TR * SW_ + ty * (SW_ + 4) + tx + (ND - 1);   // window top-left, d = 0
+    float lm[25];
+#pragma unroll
+    for (int k = 0; k < 25; ++k) lm[k] = (float)a.l[(yb - 2 + k / 5) * W + xb - 2 + k % 5] - mlv;
+    const int jmax = xb - kZW / 2;
+    // sliding 5x5 window of the right image: relative column q (step d needs -d .. -d+4) lives in slot q mod 5
+    float win[5][5];
+#pragma unroll
+    for (int wh = 0; wh < 5; ++wh)
+#pragma unroll
+        for (int q = 1; q < 5; ++q) win[wh][(((q - D0) % 5) + 5) % 5] = si[wh * (SW_ + 4) + q - D0];      // columns 1..4 of step d = D0
+#pragma unroll
+    for (int d0 = D0; d0 < D1; d0 += 8) {
+        if (d0 < nd) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int d = d0 + u;
+                // new leftmost column (relative column -d) goes to slot (-d) mod 5 = (5 - d % 5) % 5
+                const int s0 = (5 - d % 5) % 5;
+#pragma unroll
+                for (int wh = 0; wh < 5; ++wh) win[wh][s0] = si[wh * (SW_ + 4) - d];
+                const float mrv = sm[-d];
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 25; ++k) {
+                    float t = lm[k] - win[k / 5][(s0 + k % 5) % 5];
+                    t = t + mrv;
+                    acc = acc + fabsf(t);
+                }
+                c[d] = (d <= jmax) ? acc : kSentinel;
+                __builtin_amdgcn_sched_barrier(0);      // keeps the LDS reads of later steps from being hoisted (registers)
+            }
+        }
+    }
+}
+
 // Pass 1: the nd raw costs of bordered pixel (yb, xb) = tile row ty, tile column tx, into registers.  The border (>= 6) makes
 // every window of a cropped pixel spatially valid, so only the disparity range is tested: census d <= xb - 5
 // (matchers.cpp:318), the others d <= window-left column.  M == 2 reads the parked Sobel-SAD costs [nd][Hc][Wc] through
@@ -439,42 +487,7 @@ __device__ __forceinline__ void raw_costs(const FastArgs& a, const unsigned char
             }
         }
     } else {
-        const float mlv = a.ml[pl];
-        const float* sm = reinterpret_cast<const float*>(smem) + ty * SW_ + tx + (ND - 1);
-        const float* si = reinterpret_cast<const float*>(smem) + TR * SW_ + ty * (SW_ + 4) + tx + (ND - 1);   // window top-left, d = 0
-        float lm[25];
-#pragma unroll
-        for (int k = 0; k < 25; ++k) lm[k] = (float)a.l[(yb - 2 + k / 5) * W + xb - 2 + k % 5] - mlv;
-        const int jmax = xb - kZW / 2;
-        // sliding 5x5 window of the right image: win[wh][(col) % 5]; step d needs columns -d .. -d+4 relative to si
-        float win[5][5];
-#pragma unroll
-        for (int wh = 0; wh < 5; ++wh)
-#pragma unroll
-            for (int q = 1; q < 5; ++q) win[wh][q] = si[wh * (SW_ + 4) + q];      // columns 1..4 of step d = 0
-#pragma unroll
-        for (int d0 = 0; d0 < ND; d0 += 8) {
-            if (d0 < nd) {
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const int d = d0 + u;
-                    // new leftmost column (relative column -d) goes to slot (-d) mod 5 = (5 - d % 5) % 5
-                    const int s0 = (5 - d % 5) % 5;
-#pragma unroll
-                    for (int wh = 0; wh < 5; ++wh) win[wh][s0] = si[wh * (SW_ + 4) - d];
-                    const float mrv = sm[-d];
-                    float acc = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 25; ++k) {
-                        float t = lm[k] - win[k / 5][(s0 + k % 5) % 5];
-                        t = t + mrv;
-                        acc = acc + fabsf(t);
-                    }
-                    c[d] = (d <= jmax) ? acc : kSentinel;
-                    __builtin_amdgcn_sched_barrier(0);      // keeps the LDS reads of later steps from being hoisted (registers)
-                }
-            }
-        }
+        zsad_costs<ND, TR, 0, ND>(a, smem, tx, ty, xb, yb, nd, c);
     }
 }
 
@@ -582,8 +595,15 @@ template <int ND> constexpr size_t features_cl_strip_bytes() {
     return ((m0 > m1 ? (m0 > m3 ? m0 : m3) : (m1 > m3 ? m1 : m3)) + 15) & ~(size_t)15;
 }
 
+// ZSPLIT (ND = 96): the ZSAD wave's raw-cost pass -- 25 window terms x 3 dependent fp32 operations per disparity -- is twice any
+// other matcher's and the other three waves wait for it at the first tile barrier.  The Sobel-SAD wave, whose own pass 1 is 96
+// loads of parked costs, first forms the ZSAD costs of the UPPER half of the disparity range from the ZSAD wave's strips
+// (`zstrip`) and hands them over through the second tile buffer, which no wave writes before the first tile barrier; the ZSAD
+// wave forms the lower half.  Every cost is the same chain of operations whichever wave runs it: bit-identical output.
 template <int M, int ND>
-__device__ __forceinline__ void features_cl_wave(const FastArgs& a, unsigned char* strip, float* tbuf, const float* park_base) {
+__device__ __forceinline__ void features_cl_wave(const FastArgs& a, unsigned char* strip, float* tbuf, const float* park_base,
+                                                 const unsigned char* zstrip) {
+    constexpr bool ZSPLIT = ND == 96;
     const int tid = threadIdx.x, lane = tid & 63;
     const int xc0 = blockIdx.x * 64, y = blockIdx.y;
     const int nd = a.nd;
@@ -597,7 +617,26 @@ __device__ __forceinline__ void features_cl_wave(const FastArgs& a, unsigned cha
     const __amdgpu_buffer_rsrc_t o_all = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)((unsigned)nd * plane4 * 8u), 0x00020000);
 
     float c[ND];
-    raw_costs<M, ND, 1>(a, strip, x - xc0, 0, x + a.bw, y + a.bh, nd, park, pix4, plane4, c);
+    float* const hand = tbuf + 64 * kClPitch;              // the second tile buffer: [ND / 2][64] floats of hand-over
+    if constexpr (ZSPLIT && M == 3) {
+        zsad_costs<ND, 1, 0, ND / 2>(a, strip, x - xc0, 0, x + a.bw, y + a.bh, nd, c);
+    } else if constexpr (ZSPLIT && M == 2) {
+        zsad_costs<ND, 1, ND / 2, ND>(a, zstrip, x - xc0, 0, x + a.bw, y + a.bh, nd, c);
+#pragma unroll
+        for (int d = ND / 2; d < ND; ++d)
+            if (d < nd) hand[(d - ND / 2) * 64 + lane] = c[d];
+        raw_costs<M, ND, 1>(a, strip, x - xc0, 0, x + a.bw, y + a.bh, nd, park, pix4, plane4, c);
+    } else {
+        raw_costs<M, ND, 1>(a, strip, x - xc0, 0, x + a.bw, y + a.bh, nd, park, pix4, plane4, c);
+    }
+    if constexpr (ZSPLIT) {
+        __syncthreads();                                   // the upper half of the ZSAD costs is in `hand`
+        if constexpr (M == 3) {
+#pragma unroll
+            for (int d = ND / 2; d < ND; ++d)
+                if (d < nd) c[d] = hand[(d - ND / 2) * 64 + lane];
+        }
+    }
     float m = kSentinel;
 #pragma unroll
     for (int d = 0; d < ND; ++d)
@@ -666,12 +705,13 @@ __global__ __launch_bounds__(256, 3) void features_cl_kernel(FastArgs a, const f
     __shared__ __attribute__((aligned(16))) float tbuf[2 * 64 * kClPitch];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     unsigned char* strip = strips + wave * SB;
+    const unsigned char* zstrip = strips + ((0 - blockIdx.x - blockIdx.y) & 3) * SB;      // the strips of this block's ZSAD wave
     // the long-running ZSAD wave rotates over the four SIMDs from block to block
     switch ((wave + blockIdx.x + blockIdx.y) & 3) {
-    case 0: features_cl_wave<3, ND>(a, strip, tbuf, park); break;
-    case 1: features_cl_wave<1, ND>(a, strip, tbuf, park); break;
-    case 2: features_cl_wave<0, ND>(a, strip, tbuf, park); break;
-    default: features_cl_wave<2, ND>(a, strip, tbuf, park); break;
+    case 0: features_cl_wave<3, ND>(a, strip, tbuf, park, zstrip); break;
+    case 1: features_cl_wave<1, ND>(a, strip, tbuf, park, zstrip); break;
+    case 2: features_cl_wave<0, ND>(a, strip, tbuf, park, zstrip); break;
+    default: features_cl_wave<2, ND>(a, strip, tbuf, park, zstrip); break;
     }
 }
 
