@@ -12,6 +12,14 @@
  * NCC arithmetic.  (The survey's out-of-tree probe reported bit-exact agreement of an equivalent NumPy
  * restatement with the compiled reference on a 37x53, D=12 pair; that probe is not reproducible here.)
  *
+ * What IS pinned around this file (round 6): the reference's own Python glue -- cbmv_generator.py get_costs :27-79,
+ * extract_features_left :258-308, extract_features_lr :84-254, imported unmodified -- is run by
+ * tests/golden/make_volume_golden.py with THESE functions served as its src.cpp.lib.libmatchers / libfeatextract, and
+ * its outputs are committed as tests/golden/volume_*.npz.  That pins oracle/ms_volume.py's restated glue (rows a7, a9,
+ * f2: windows, swap_axes placement, crop, clip / normalise, float64 scratch, sad_sigma on the Sobel channel,
+ * right-cost order, transposes) to the reference bit for bit GIVEN these natives.  It says nothing about the natives
+ * themselves (rows a1-a6, a8): both sides of that comparison call this file.
+ *
  * Build: see oracle/Makefile (-O2 -ffp-contract=off: no FMA contraction, no re-association).
  */
 #include <math.h>

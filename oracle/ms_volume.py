@@ -1,6 +1,9 @@
 """ORACLE (test infrastructure, not product code): NumPy/ctypes front-end of oracle/matchers_oracle.c with
 the reference's Python glue restated.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
-leg may import this.  PARITY UNPINNED for the matcher half (see matchers_oracle.c header).
+leg may import this.  PARITY UNPINNED for the natives (census ... extract_likelihood: see matchers_oracle.c header).
+The Python glue below (get_costs, extract_features_left, extract_features_lr, build_ms_volume) IS pinned, bit for bit, to
+the reference's own cbmv_generator.py run around these natives: tests/golden/volume_*.npz, made by
+tests/golden/make_volume_golden.py, checked by tests/test_golden_volume.py.
 
 Restated reference functions (paths under /root/reference/src):
   libmatchers.census / nccNister / zsad / sobel / sadsob  cpp/matchers/matchers.cpp:565-580

@@ -149,3 +149,51 @@ def full_input(case):
     """Input volume of a FULL_CASES entry: torch.rand, or (ms_volume) the oracle's MS volume of the seeded synthetic pair --
     the caller passes it in because this file must not import oracle/ (the tests do)."""
     return make_input(case["in_shape"], case["seed"])
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Round 6: the matching-space volume cases of tests/golden/make_volume_golden.py (the reference's own Python glue,
+# cbmv_generator.py:27-79,84-254,258-308, around the oracle's natives).  Three tiny bordered pairs: uniform noise, a shifted
+# texture (census / ZSAD minima at a planted disparity), and large constant regions (NCC's non-finite branch, all-equal
+# census windows, all-sentinel rows in the left D' columns).
+VOLUME_CASES = {
+    "random": dict(kind="random", seed=61, hw=(36, 56), ndisp=12, board=10),
+    "shifted": dict(kind="shifted", seed=62, hw=(40, 64), ndisp=16, board=10),
+    "flat": dict(kind="flat", seed=63, hw=(33, 47), ndisp=8, board=10),
+}
+
+
+def volume_pair(case):
+    """-> bordered uint8 images [h + 2b, w + 2b] x 2 of a VOLUME_CASES entry (the fixtures store them too)."""
+    h, w = case["hw"]
+    nd, b = case["ndisp"], case["board"]
+    rng = np.random.default_rng(case["seed"])
+    if case["kind"] == "random":
+        l = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        r = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    elif case["kind"] == "shifted":
+        base = rng.integers(0, 256, (h + 2, w + nd + 2)).astype(np.float32)
+        sm = sum(base[dy:dy + h, dx:dx + w + nd] for dy in range(3) for dx in range(3)) / 9.0
+        base = np.clip(np.rint(sm), 0, 255).astype(np.uint8)
+        shift = np.where(np.arange(h) < h // 2, 5, nd - 3)            # two row bands, two disparities
+        l = base[:, :w]
+        r = np.stack([base[y, shift[y]: shift[y] + w] for y in range(h)])   # right[x] = left[x + d]
+    elif case["kind"] == "flat":
+        l = np.full((h, w), 90, np.uint8)
+        r = np.full((h, w), 90, np.uint8)
+        l[: h // 2, : w // 2] = rng.integers(0, 256, (h // 2, w // 2), dtype=np.uint8)
+        r[h // 3:, w // 3:] = rng.integers(0, 256, (h - h // 3, w - w // 3), dtype=np.uint8)
+        l[-6:, -9:] = 255                                              # a saturated corner next to the zero border
+    else:
+        raise ValueError(case["kind"])
+    pad = lambda a: np.pad(a, ((b, b), (b, b)), "constant").astype(np.uint8).copy(order="C")  # noqa: E731
+    return pad(l), pad(r)
+
+
+def arrays_sha256(arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.shape).encode() + str(a.dtype).encode())
+        h.update(a.tobytes())
+    return h.digest()
