@@ -151,7 +151,7 @@ int msnet_ncdhw_to_ndhwc(const float* src, float* dst, int N, int C, int D, int 
 int msnet_ndhwc_to_ncdhw(const float* src, float* dst, int N, int C, int D, int H, int W,
                          msnet_stream_t stream);
 /* Range check of a module input that already IS channels-last (no conversion pass to carry it): one read of `count` floats
- * (16-byte aligned, count % 4 == 0); raises bit 1 of the calling thread's overflow word (msnet_set_overflow_flag) when a value
+ * (any count >= 1, any float alignment: whole float4 reads between scalar edges); raises bit 1 of the calling thread's overflow word (msnet_set_overflow_flag) when a value
  * is outside the split-fp16 kernels' range (|x| >= 32752) or not finite.  A no-op without a registered word.  Entry of
  * PSMNet_CostVolumeAggre.forward_ndhwc for the reference's 64-plane volume (psmnet_3dcnn.py:126-131). */
 int msnet_check_input_range(const float* x, size_t count, msnet_stream_t stream);
@@ -220,6 +220,13 @@ int msnet_conv3d_k3_c8_ncdhw_f16s(const float* x_ncdhw, const void* wpk_f16s, co
  * overflow word), which the layout-conversion pass carries on the NCDHW route.  Entry of GCNet_CostVolumeAggre.forward_ndhwc. */
 int msnet_conv3d_k3_c8_in_f16s(const float* x_ndhwc, const void* wpk_f16s, const float* scale, const float* shift,
                                float* y, int N, int D, int H, int W, int Co, int relu, msnet_stream_t stream);
+/* Stride-1 conv (no residual) on a channels-last module input of ANY supported width, x: f32[N][D][H][W][Ci] ->
+ * y: NDHWC f32[N][D][H][W][Co], with the range check of the module INPUT (bit 1 of the overflow word).  Entry of
+ * PSMNet_CostVolumeAggre.forward_ndhwc for dres0.0 on the reference's 64-plane volume (psmnet_3dcnn.py:96-99,126-131): the
+ * tiled Co = 32 kernel checks the values its loaders stage, so the volume is read once; shapes that kernel does not take run
+ * msnet_check_input_range + msnet_conv3d_k3_f16s.  Same bits as msnet_conv3d_k3_f16s. */
+int msnet_conv3d_k3_in_f16s(const float* x_ndhwc, const void* wpk_f16s, const float* scale, const float* shift, float* y,
+                            int N, int D, int H, int W, int Ci, int Co, int relu, msnet_stream_t stream);
 /* Conv3d(Ci->1, k3, p1, bias=False) head (psmnet_3dcnn.py:112-122 classif*.2), optional "+ add"
  * (cost2 = classif2(out2) + cost1, :146-147).  x: NDHWC; w: f32[1][Ci][3][3][3]; y/add: f32[N][D][H][W].
  * y = wscale * conv(x, w) (+ add): the caller may hand over the weights multiplied by a power of two (so that their fp16

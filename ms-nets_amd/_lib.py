@@ -70,6 +70,7 @@ SIGNATURES = {
     "msnet_conv3d_k3_wd_f16s_strided": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_conv3d_k3_c8_ncdhw_f16s": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_conv3d_k3_c8_in_f16s": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, P]),
+    "msnet_conv3d_k3_in_f16s": (c_int, [P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_conv3d_k3_cout1": (c_int, [P, P, c_float, P, P, c_int, c_int, c_int, c_int, c_int, P]),
     "msnet_softargmin": (c_int, [P, P, c_int, c_int, c_int, c_int, P]),
     "msnet_deconv5_softargmin": (c_int, [P, P, c_float, c_float, P, c_int, c_int, c_int, c_int, c_int, P]),

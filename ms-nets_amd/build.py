@@ -3,6 +3,7 @@ C-ABI shared object (include/msnet_hip.h) that is loaded with ctypes.
 
     python -m ms-nets_amd.build            # or: from __graft_entry__ import build; build()
 """
+import fcntl
 import hashlib
 import os
 import subprocess
@@ -56,6 +57,26 @@ def _digest(paths, extra=()):
     return h.hexdigest()
 
 
+_compiler_id = {}
+
+
+def _compiler_identity(hipcc):
+    """`hipcc --version` (HIP / clang version, install dir): a ROCm upgrade must not reuse the old compiler's objects."""
+    if hipcc not in _compiler_id:
+        try:
+            _compiler_id[hipcc] = subprocess.run([hipcc, "--version"], capture_output=True, text=True, timeout=120).stdout.strip()
+        except (OSError, subprocess.SubprocessError):
+            _compiler_id[hipcc] = "unknown"
+    return _compiler_id[hipcc]
+
+
+def _write_stamp(stamp, digest):
+    tmp = "%s.%d.tmp" % (stamp, os.getpid())
+    with open(tmp, "w") as f:
+        f.write(digest + "\n")
+    os.replace(tmp, stamp)                              # atomic: a concurrent reader sees the old stamp or the new one
+
+
 def _stale(target, stamp, digest):
     """An object is reused only if it exists AND was compiled from exactly these bytes with exactly this command (its .sha
     stamp): modification times say nothing on a box that received the tree by copy."""
@@ -73,6 +94,16 @@ def build(force=False, verbose=True, defines=(), lib=None):
     objdir = os.path.join(HERE, "build" + tag)
     out = lib or LIB                                   # (a variant's path must not stick to later default builds)
     os.makedirs(objdir, exist_ok=True)
+    # several ranks of one launch may call build() at once: one builds, the others wait and then find fresh stamps
+    with open(os.path.join(objdir, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(hipcc, objdir, out, force, verbose, defines)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(hipcc, objdir, out, force, verbose, defines):
     headers = [os.path.join(CSRC, h) for h in ("common.h", "conv_common.h", "conv_f16s.h", "conv_f16s_ws.h")] + [
         os.path.join(HERE, "..", "include", "msnet_hip.h")]
     objs, procs, stamps = [], [], {}
@@ -81,10 +112,14 @@ def build(force=False, verbose=True, defines=(), lib=None):
         op = os.path.join(objdir, src + ".o")
         objs.append(op)
         cmd = [hipcc, "-x", "hip"] + COMMON + extra + ["-D" + d for d in defines] + ["-c", sp, "-o", op]
-        digest = _digest([sp] + headers, cmd[1:-1])     # (not the compiler's path, not the output path)
+        # flags + the source's NAME (not its absolute path: a tree copied elsewhere reuses its objects) + the compiler's identity
+        flags = ["-x", "hip"] + COMMON + extra + ["-D" + d for d in defines]
+        digest = _digest([sp] + headers, flags + [src, _compiler_identity(hipcc)])
         if force or _stale(op, op + ".sha", digest):
-            if os.path.exists(op + ".sha"):
+            try:
                 os.remove(op + ".sha")
+            except FileNotFoundError:
+                pass
             if verbose:
                 print("[build]", " ".join(cmd), flush=True)
             procs.append((src, subprocess.Popen(cmd)))
@@ -93,16 +128,14 @@ def build(force=False, verbose=True, defines=(), lib=None):
     if failed:
         raise RuntimeError("hipcc failed for: " + ", ".join(failed))
     for src, (stamp, digest) in stamps.items():
-        with open(stamp, "w") as f:
-            f.write(digest + "\n")
+        _write_stamp(stamp, digest)
     link_digest = _digest(objs, [ARCH])
     if force or procs or _stale(out, out + ".sha", link_digest):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=" + ARCH, "-o", out] + objs
         if verbose:
             print("[build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
-        with open(out + ".sha", "w") as f:
-            f.write(link_digest + "\n")
+        _write_stamp(out + ".sha", link_digest)
     build.last_compiled = [s for s, _ in procs]
     if verbose:
         print("[build] %s: compiled %d of %d sources (%s), objects keyed by content sha256" % (

@@ -71,12 +71,21 @@ bool LaunchScope::events(hipEvent_t* start, hipEvent_t* stop) const {
     if (!rec || !attach) return false;
     Rec* r = static_cast<Rec*>(rec);
     *start = r->a; *stop = r->b;
+    launched = true;
     return true;
 }
 
 LaunchScope::~LaunchScope() {
     if (!rec) return;
     Rec* r = static_cast<Rec*>(rec);
+    if (attach && !launched) {
+        // an early return between the scope and its one launch: the pair was never recorded -- querying it later would leave a
+        // sticky HIP error for the next check_launch() to report as a failure that never happened
+        (void)hipEventDestroy(r->a);
+        (void)hipEventDestroy(r->b);
+        delete r;
+        return;
+    }
     if (!attach) (void)hipEventRecord(r->b, stream);
     std::lock_guard<std::mutex> lk(g_mu);
     g_recs.push_back(r);
@@ -124,6 +133,8 @@ extern "C" long msnet_prof_collect(char* buf, size_t n) {
         if (hipEventSynchronize(r->b) == hipSuccess && hipEventElapsedTime(&ms, r->a, r->b) == hipSuccess) {
             Agg& g = agg[r->name];
             g.calls++; g.ms += ms; g.flops += r->flops; g.bytes += r->bytes;
+        } else {
+            (void)hipGetLastError();          // a row that cannot be read is dropped, not left behind as a sticky error
         }
         (void)hipEventDestroy(r->a);
         (void)hipEventDestroy(r->b);

@@ -33,6 +33,7 @@ struct LaunchScope {
     ~LaunchScope();
     bool events(hipEvent_t* start, hipEvent_t* stop) const;       // attach mode, profiling on: the pair to hand to the launch
     const char* name; hipStream_t stream; void* rec; bool attach;
+    mutable bool launched = false;      // attach mode: events() handed the pair to a launch (else the pair was never recorded)
 };
 // one kernel under an attach-mode scope: hipExtLaunchKernelGGL with the scope's events when this launch is being timed
 #define MSNET_LAUNCH(ls, kernel, grid, block, lds, stream, ...)                                                        \

@@ -101,3 +101,26 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
     }
     return ws_launch_co32("conv3d_s1_f16s_co32", a, s);
 }
+
+// Stride-1 conv (no residual) on a channels-last MODULE INPUT x: f32[N][D][H][W][Ci] with the fp16-range check of that input
+// (bit 1 of the calling thread's overflow word) -- PSMNet_CostVolumeAggre.forward_ndhwc's dres0.0 on the reference's 64-plane
+// volume (psmnet_3dcnn.py:96-99,126-131).  Shapes the tiled Co = 32 kernel takes carry the check in their loaders (round 6: no
+// separate pass over the volume); every other shape runs msnet_check_input_range in front of msnet_conv3d_k3_f16s.  Same bits as
+// msnet_conv3d_k3_f16s either way.
+extern "C" int msnet_check_input_range(const float* x, size_t count, msnet_stream_t stream);
+extern "C" int msnet_conv3d_k3_in_f16s(const float* x_ndhwc, const void* wpk_f16s, const float* scale, const float* shift, float* y,
+                                       int N, int D, int H, int W, int Ci, int Co, int relu, msnet_stream_t stream) {
+    if (!x_ndhwc || !wpk_f16s || !y) return fail("msnet_conv3d_k3_in_f16s: null pointer");
+    if (N <= 0 || D <= 0 || H <= 0 || W <= 0) return fail("msnet_conv3d_k3_in_f16s: empty input");
+    if (!msnet_conv3d_k3_f16s_supported(Ci, Co, 1)) return fail("msnet_conv3d_k3_in_f16s: unsupported shape Ci=%d Co=%d", Ci, Co);
+    ConvArgs a{};
+    a.x = x_ndhwc; a.wpk = reinterpret_cast<const f32x4*>(wpk_f16s); a.scale = scale; a.shift = shift; a.res = nullptr; a.y = y;
+    a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = Ci; a.Co = Co; a.relu = relu; a.oflag = overflow_flag();
+    a.OD = D; a.OH = H; a.OW = W;
+    const size_t items = (size_t)cdiv(D, 2) * cdiv(H, 4) * cdiv(W, 32);       // of ONE sample, as msnet_conv3d_k3_f16s counts them
+    if (Co == 32 && Ci % 32 == 0 && Ci > 32 && !direct_eligible(a, items))
+        return ws_launch_co32_inchk("conv3d_s1_f16s_co32", a, (hipStream_t)stream);
+    const int rc = msnet_check_input_range(x_ndhwc, (size_t)N * D * H * W * Ci, stream);
+    if (rc) return rc;
+    return msnet_conv3d_k3_f16s(x_ndhwc, wpk_f16s, scale, shift, nullptr, y, N, D, H, W, Ci, Co, 1, relu, stream);
+}

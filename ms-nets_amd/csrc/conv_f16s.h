@@ -182,6 +182,7 @@ int ws_launch_c16(bool co64, const char* name, ConvArgs a, hipStream_t s);      
 int ws_launch_co64(bool w16, const char* name, ConvArgs a, hipStream_t s);          // conv3d_f16s_ws_co64.hip
 int ws_launch_co32(const char* name, ConvArgs a, hipStream_t s);                    // conv3d_f16s_ws_co32.hip
 int ws_launch_co32_slide(const char* name, ConvArgs a, hipStream_t s);              // conv3d_f16s_ws_co32.hip
+int ws_launch_co32_inchk(const char* name, ConvArgs a, hipStream_t s);              // conv3d_f16s_ws_co32.hip
 int c8_launch(int nb, bool ncs, bool inchk, const char* name, ConvArgs a, hipStream_t s);      // conv3d_f16s_c8.hip
 int c8_pack_launch(const float* w, _Float16* packed, int Co, hipStream_t s);        // conv3d_f16s_c8.hip
 int direct_launch(bool transposed, const char* name, ConvArgs a, int stride, int KS, int NBG, hipStream_t s);   // conv3d_f16s_direct.hip

@@ -18,9 +18,14 @@ namespace msnet {
 // (p + 2j) & 3); only the two new planes are fetched, split and copied -- into the slots of the two planes that die
 // first -- and the two-barrier staging window between tiles is empty except at the start of a column.
 // LW = loader waves (4, or 8 for the stride-2 layers whose staging work per MFMA is 2.5x that of the stride-1 layers).
-template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB, int STRIDE, bool SLIDE = false, int LW = 4>
+// INCHK (round 6): the input IS a module input (PSMNet's 64-plane volume handed over channels-last): the loaders fold the magnitude
+// bits of every staged value into the fp16-range check of the module input (bit 1 of the overflow word, like the first-layer
+// kernel) -- the separate read-only pass over the volume (msnet_check_input_range, 0.08 ms at 48x136x240x64) is not needed then.
+template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB, int STRIDE, bool SLIDE = false, int LW = 4,
+          bool INCHK = false>
 __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k3s1_f16s_ws(ConvArgs a) {
     constexpr int LT = 64 * LW;                          // loader threads
+    static_assert(!INCHK || (!RESB && !SLIDE && STRIDE == 1), "input check: plain stride-1 tiles (every staged value passes write_a's split)");
     static_assert(!SLIDE || (STRIDE == 1 && !RESB && !SWZ && TD == 2), "sliding window: stride 1, streamed weights, padded records");
     constexpr int CC = 16 * KS;
     constexpr int BH = 32 / BW;
@@ -199,6 +204,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
         };
         // split + copy slots [u0, u1) of the register set `src` into LDS plane slot `pslot` (a run-time value in the sliding kernel).
         // pre = true: the set already holds hi|lo fp16 quads (presplit below), only the two LDS stores are left.
+        [[maybe_unused]] unsigned in_amax = 0u;         // INCHK: running max of the staged values' magnitude BITS (inf / NaN compare high)
         auto write_a = [&](const f32x4 (&src)[PL], int pslot, int u0, int u1, auto prec) {
             constexpr bool PRE = decltype(prec)::value;
             struct H2 { half4 a, b; };
@@ -209,6 +215,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                     half4 hi, lo;
                     if constexpr (PRE) { const H2 t = __builtin_bit_cast(H2, src[u]); hi = t.a; lo = t.b; }
                     else split4(src[u], hi, lo);
+                    if constexpr (INCHK && !PRE)
+                        in_amax = max(max(in_amax, max(magnitude_bits(src[u][0]), magnitude_bits(src[u][1]))),
+                                      max(magnitude_bits(src[u][2]), magnitude_bits(src[u][3])));
                     const int off = pslot * (IH * IW * RB) + ((SWZ || CPERM) ? lsw_[u] : lhi0 + u * (LT / VR) * RB);
                     *reinterpret_cast<half4*>(lds + off) = hi;
                     *reinterpret_cast<half4*>(lds + (SWZ ? (off ^ HB) : off + HB)) = lo;
@@ -462,6 +471,9 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
 #undef MSNET_WRITE_B
 #undef MSNET_ISSUE_B
 #undef MSNET_SETI
+        if constexpr (INCHK) {
+            if (a.oflag && in_amax >= kSplitMaxBits) atomicOr(a.oflag, 2u);
+        }
         return;
     }
 
@@ -855,7 +867,7 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
     if (pending) epilogue(pn, pod0, poh0, pow0, pcg);
 }
 
-template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB, int STRIDE = 1, int LW = 4>
+template <int TD, int TH, int TW, int BW, int MB, int NB, bool SWZ, int KS, bool RESB, int STRIDE = 1, int LW = 4, bool INCHK = false>
 int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     a.ntd = cdiv(a.OD, TD); a.nth = cdiv(a.OH, TH); a.ntw = cdiv(a.OW, TW);
     a.ngroups = a.Co / (32 * NB); a.nbtot = a.Co / 32;
@@ -867,7 +879,7 @@ int launch_f16s(const char* name, ConvArgs a, hipStream_t s) {
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
                    4.0 * ((double)a.N * a.D * a.H * a.W * a.Ci + vox * a.Co * (a.res ? 2 : 1)), true);
-    MSNET_LAUNCH(ls, (conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB, SWZ, KS, RESB, STRIDE, false, LW>), dim3((unsigned)nblk), dim3(256 + 64 * LW), 0, s, a);
+    MSNET_LAUNCH(ls, (conv3d_k3s1_f16s_ws<TD, TH, TW, BW, MB, NB, SWZ, KS, RESB, STRIDE, false, LW, INCHK>), dim3((unsigned)nblk), dim3(256 + 64 * LW), 0, s, a);
     return check_launch(name);
 }
 

@@ -88,8 +88,15 @@ __device__ __forceinline__ unsigned mag4(u32x4_p v) {
     v &= 0x7fffffffu;
     return max(max(v.x, v.y), max(v.z, v.w));
 }
-__global__ __launch_bounds__(256) void input_range_kernel(const u32x4_p* __restrict__ x, size_t n4, unsigned* oflag) {
+// (edge: up to 3 floats in front of the first 16-byte boundary and up to 3 behind the last whole float4, scalar reads by block 0)
+__global__ __launch_bounds__(256) void input_range_kernel(const u32x4_p* __restrict__ x, size_t n4, unsigned* oflag,
+                                                          const unsigned* __restrict__ head, int nhead,
+                                                          const unsigned* __restrict__ tail, int ntail) {
     unsigned amax = 0u;
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < nhead) amax = head[threadIdx.x] & 0x7fffffffu;
+        if ((int)threadIdx.x < ntail) amax = max(amax, tail[threadIdx.x] & 0x7fffffffu);
+    }
     const size_t stride = (size_t)gridDim.x * 256;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     for (; i + 3 * stride < n4; i += 4 * stride) {         // four independent 16-byte loads in flight per thread
@@ -107,14 +114,19 @@ using namespace msnet;
 
 extern "C" int msnet_check_input_range(const float* x, size_t count, msnet_stream_t stream) {
     if (!x) return fail("msnet_check_input_range: null pointer");
-    if (count == 0 || count % 4 || ((uintptr_t)x & 15)) return fail("msnet_check_input_range: %zu floats (a 16-byte aligned multiple of 4)", count);
+    if (count == 0 || ((uintptr_t)x & 3)) return fail("msnet_check_input_range: %zu floats at %p (needs a non-empty float array)", count, (const void*)x);
     unsigned* of = overflow_flag();
     if (!of) return 0;                                     // no guard registered on this thread: nothing to report to
     hipStream_t s = (hipStream_t)stream;
-    const size_t n4 = count / 4;
+    // any length, any float alignment: scalar reads up to the first 16-byte boundary and behind the last whole float4
+    size_t nhead = ((16 - ((uintptr_t)x & 15)) & 15) / 4;
+    if (nhead > count) nhead = count;
+    const size_t n4 = (count - nhead) / 4, ntail = count - nhead - 4 * n4;
+    const float* body = x + nhead;
     const unsigned blocks = (unsigned)((n4 + 1023) / 1024 < 4096 ? (n4 + 1023) / 1024 : 4096);
     LaunchScope ls("input_range_check", s, 0, 4.0 * count);
-    hipLaunchKernelGGL(input_range_kernel, dim3(blocks), dim3(256), 0, s, reinterpret_cast<const u32x4_p*>(x), n4, of);
+    hipLaunchKernelGGL(input_range_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, reinterpret_cast<const u32x4_p*>(body), n4, of,
+                       reinterpret_cast<const unsigned*>(x), (int)nhead, reinterpret_cast<const unsigned*>(body + 4 * n4), (int)ntail);
     return check_launch("msnet_check_input_range");
 }
 

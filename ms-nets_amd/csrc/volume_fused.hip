@@ -846,6 +846,7 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
     LaunchScope whole("vol_build", s, 0, 4.0 * 8.0 * nd * (double)plane + 2.0 * img, true);
     hipEvent_t ev_first = nullptr, ev_last = nullptr;
     const bool timed = whole.events(&ev_first, &ev_last);
+    whole.launched = false;        // the stop event rides on the LAST kernel: an early return before it drops the row (common.h)
     {
         LaunchScope ls("volk_prep", s, 0, 2.0 * img + 72.0 * img);
         if (timed) hipExtLaunchKernelGGL(vprep_kernel, dim3(cdiv(Wb, 64), cdiv(Hb, 4), 3), dim3(256), 0, s, ev_first, nullptr, 0, a);
@@ -892,6 +893,7 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
     auto features = [&](int zbase, int nz, bool last) {
         const dim3 g(gpix.x, gpix.y, nz);
         hipEvent_t stop = (last && timed) ? ev_last : nullptr;
+        if (stop) whole.launched = true;
         if (nd <= 32) { if (stop) hipExtLaunchKernelGGL(features4_kernel<32>, g, dim3(256), 0, s, nullptr, stop, 0, a, zbase);
                         else hipLaunchKernelGGL(features4_kernel<32>, g, dim3(256), 0, s, a, zbase); }
         else          { if (stop) hipExtLaunchKernelGGL(features4_kernel<96>, g, dim3(256), 0, s, nullptr, stop, 0, a, zbase);
@@ -901,6 +903,7 @@ int volume_fast_launch(const uint8_t* l, const uint8_t* r, int Hb, int Wb, int n
         LaunchScope ls("volk_features", s, 0, 4.0 * 8.0 * nd * (double)plane);
         const dim3 g(gpix.x, a.Hc, 1);
         hipEvent_t stop = timed ? ev_last : nullptr;
+        if (stop) whole.launched = true;
         if (nd <= 32) { if (stop) hipExtLaunchKernelGGL(features_cl_kernel<32>, g, dim3(256), 0, s, nullptr, stop, 0, a, (const float*)park_ws);
                         else hipLaunchKernelGGL(features_cl_kernel<32>, g, dim3(256), 0, s, a, park_ws); }
         else          { if (stop) hipExtLaunchKernelGGL(features_cl_kernel<96>, g, dim3(256), 0, s, nullptr, stop, 0, a, (const float*)park_ws);

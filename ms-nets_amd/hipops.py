@@ -308,10 +308,8 @@ def conv3d_k3(x, wpk, scale, shift, co, stride=1, relu=False, residual=None, f16
 def check_input_range(x):
     """fp16-range check of a channels-last module input (RangeGuard.INPUT), one read-only pass; returns x (contiguous)."""
     x = require_gpu_f32(x, "x").contiguous()
-    if x.numel() % 4 == 0 and x.data_ptr() % 16 == 0:
-        check(_lib.load().msnet_check_input_range(ptr(x), x.numel(), stream_ptr()), "msnet_check_input_range")
-        return x
-    raise ValueError("check_input_range: %d floats at %#x (needs a 16-byte aligned multiple of 4)" % (x.numel(), x.data_ptr()))
+    check(_lib.load().msnet_check_input_range(ptr(x), x.numel(), stream_ptr()), "msnet_check_input_range")
+    return x
 
 
 def conv3d_c8_ncdhw(x, wpk, scale, shift, co, relu=False):
@@ -336,6 +334,22 @@ def conv3d_c8_in(x, wpk, scale, shift, co, relu=False):
     y = _new((n, d, h, w, co), x.device)
     check(_lib.load().msnet_conv3d_k3_c8_in_f16s(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(y), n, d, h, w, co, int(relu),
                                                  stream_ptr()), "msnet_conv3d_k3_c8_in_f16s")
+    return y
+
+
+def conv3d_k3_in(x, wpk, scale, shift, co, relu=False):
+    """Split-fp16 stride-1 conv on a channels-last MODULE INPUT x [N,D,H,W,Ci] with the fp16-range check of that input
+    (RangeGuard.INPUT) -- inside the conv's loaders where the tiled kernel takes the shape, as one read-only pass in front of
+    it otherwise (msnet_conv3d_k3_in_f16s).  Same bits as conv3d_k3(..., f16s=True)."""
+    x = require_gpu_f32(x, "x").contiguous()
+    n, d, h, w, ci = x.shape
+    lib = _lib.load()
+    # (MSNET_IN_FUSED=0: A/B switch, the round-5 route -- a read-only range pass in front of the plain conv)
+    if not hasattr(lib, "msnet_conv3d_k3_in_f16s") or os.environ.get("MSNET_IN_FUSED", "1") == "0":     # or an older variant library
+        return conv3d_k3(check_input_range(x), wpk, scale, shift, co, relu=relu, f16s=True)
+    y = _new((n, d, h, w, co), x.device)
+    check(lib.msnet_conv3d_k3_in_f16s(ptr(x), ptr(wpk), ptr(scale), ptr(shift), ptr(y), n, d, h, w, ci, co, int(relu), stream_ptr()),
+          "msnet_conv3d_k3_in_f16s")
     return y
 
 
@@ -396,7 +410,9 @@ def deconv5_softargmin(x, w, bias, wscale=1.0):
     n, d, h, wd, ci = x.shape
     disp = torch.empty((n, 2 * h, 2 * wd), device=x.device, dtype=torch.float32)
     lib = _lib.load()
-    nbytes = int(lib.msnet_deconv5_softargmin_workspace_bytes(n, d, h, wd))
+    # (an A/B variant library named through MSNET_HIP_LIB may predate the segmented entry points: _lib.load tolerates that)
+    ws_bytes = getattr(lib, "msnet_deconv5_softargmin_workspace_bytes", None)
+    nbytes = int(ws_bytes(n, d, h, wd)) if ws_bytes is not None and hasattr(lib, "msnet_deconv5_softargmin_ws") else 0
     if nbytes:                            # depth-segmented tail: partial softmax states of the segments (arena memory)
         ws = _new(((nbytes + 3) // 4,), x.device)
         check(lib.msnet_deconv5_softargmin_ws(ptr(x), ptr(w), float(bias), float(wscale), ptr(disp), n, d, h, wd, ci, ptr(ws), nbytes,

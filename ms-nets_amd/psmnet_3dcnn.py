@@ -133,8 +133,8 @@ class PSMNet_CostVolumeAggre(hipops.DeviceStateMixin, nn.Module):
                 c0 = conv(hipops.conv3d_c8_in(cost, p0.wpk, p0.scale, p0.shift, p0.co, relu=True), "dres0.2")
             elif not p0.f16s:                # fp32 precision: already the kernels' layout, no fp16 range to guard
                 c0 = conv(conv(cost.contiguous(), "dres0.0"), "dres0.2")
-            else:                            # (other widths on split-fp16, the reference's 64 planes: one read-only range pass in front)
-                c0 = conv(conv(hipops.check_input_range(cost), "dres0.0"), "dres0.2")
+            else:                            # other widths on split-fp16 (the reference's 64 planes): the range check rides in dres0.0's loaders
+                c0 = conv(hipops.conv3d_k3_in(cost, p0.wpk, p0.scale, p0.shift, p0.co, relu=True), "dres0.2")
         elif FUSE_INPUT_LAYOUT and p0.f16s and cost.shape[1] == 8 and p0.co in (32, 64):      # the MS volume: first layer straight from NCDHW
             c0 = conv(hipops.conv3d_c8_ncdhw(cost, p0.wpk, p0.scale, p0.shift, p0.co, relu=True), "dres0.2")
         else:

@@ -51,7 +51,7 @@ def lib():
     if v not in _libs:
         so = _SO if not v else _SO.replace(".so", "_%s.so" % v)
         if not os.path.exists(so):
-            build()
+            subprocess.check_call(["make", "-s", "-C", _HERE, os.path.basename(so)])     # a variant is built on demand
         L = ctypes.CDLL(so)
         i = ctypes.c_int
         L.oracle_census.argtypes = [_u8p, _u8p, _f32p, i, i, i, i]

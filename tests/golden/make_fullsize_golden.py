@@ -15,6 +15,17 @@ weights, same input, run again under recipes.ALT_VARIANTS -- torch.set_num_threa
 main fixture, and oneDNN switched off (ATen's vol2col + GEMM convolution; 47 GB peak for MS-GCNet: nothing else may run).  The convolutions and reductions sum in another
 order then, so |disp_alt - disp| is the reference's own fp32 summation-order noise floor at this shape: what the GPU tests
 hold the HIP-vs-reference error distribution against.
+
+    python tests/golden/make_fullsize_golden.py --f64 [case ...]      (round 6)
+
+--f64 writes tests/golden/fullsize_<case>_f64.npz for recipes.F64_CASES: the SAME unmodified reference module, same seeded weights
+and input, moved to float64 (`ref.double()`, input `.double()`): every convolution, BatchNorm, the softmax and the regression in
+double precision, i.e. the mathematically exact forward to ~1e-13.  |disp_f64 - disp| is then how far the reference's OWN float32
+forward sits from the exact answer, and |HIP - disp_f64| how far the HIP path does: the GPU tests hold the second against the
+first (a float32 implementation cannot be asked to be closer to another float32 implementation than both are to the truth).
+One harness-side memory shim, M1: ATen's float64 Conv3d on CPU is vol2col + GEMM with a [Ci*27, D*H*W] column buffer (86 GB for
+conv3dbn_2), so nn.Conv3d.forward is wrapped to run stride-1 convolutions in depth slabs (each output voxel is still computed
+by the same ATen routine from the same 27*Ci products; only the number of voxels per call changes).
 """
 import contextlib
 import io
@@ -110,6 +121,90 @@ def run_alt(name, case):
     path = os.path.join(HERE, "fullsize_%s_alt.npz" % name)
     np.savez_compressed(path, **out)
     print("  -> %s (%.2f MB)" % (os.path.basename(path), os.path.getsize(path) / 1e6), flush=True)
+
+
+F64_COLUMN_BUDGET = 6e9          # bytes of vol2col buffer per Conv3d call (M1)
+
+
+def _install_conv3d_depth_slabs():
+    """M1: nn.Conv3d.forward in depth slabs when ATen's column buffer would not fit (see the module docstring)."""
+    if getattr(torch.nn.Conv3d, "_msnet_slabs", False):
+        return
+    plain = torch.nn.Conv3d.forward
+
+    def forward(self, x):
+        n, ci, d, h, w = x.shape
+        col = ci * 27 * d * h * w * x.element_size()
+        if (x.dtype != torch.float64 or col <= F64_COLUMN_BUDGET or self.stride != (1, 1, 1) or self.kernel_size != (3, 3, 3)
+                or self.padding != (1, 1, 1) or self.dilation != (1, 1, 1) or self.groups != 1):
+            return plain(self, x)
+        step = max(1, int(d * F64_COLUMN_BUDGET / col))
+        outs = []
+        for d0 in range(0, d, step):
+            d1 = min(d, d0 + step)
+            lo, hi = max(d0 - 1, 0), min(d1 + 1, d)
+            slab = F.pad(x[:, :, lo:hi], (0, 0, 0, 0, 1 if d0 == 0 else 0, 1 if d1 == d else 0))     # zero halo at the ends
+            outs.append(F.conv3d(slab, self.weight, self.bias, 1, (0, 1, 1)))
+        return torch.cat(outs, 2)
+    torch.nn.Conv3d.forward = forward
+    torch.nn.Conv3d._msnet_slabs = True
+
+
+def run_f64(name, case):
+    """The reference in float64 -> fullsize_<name>_f64.npz (see the module docstring)."""
+    t0 = time.time()
+    torch.set_num_threads(8)
+    gold = np.load(os.path.join(HERE, "fullsize_%s.npz" % name))
+    with contextlib.redirect_stdout(io.StringIO()):
+        ref = recipes.build_case(case, ref_gc.GCNet_CostVolumeAggre, ref_psm.PSMNet_CostVolumeAggre)
+    assert recipes.state_sha256(ref.state_dict()) == str(gold["state_sha256"])
+    x = case_input(case)
+    H, W = recipes.out_hw(case)
+    _install_conv3d_depth_slabs()
+    # self-check of M1 on a small float64 volume: slabs == one call, to the last bit or two of a double
+    conv = torch.nn.Conv3d(8, 16, 3, padding=1, bias=False).double()
+    xs = torch.rand(1, 8, 12, 10, 14, dtype=torch.float64)
+    global F64_COLUMN_BUDGET
+    keep_budget, F64_COLUMN_BUDGET = F64_COLUMN_BUDGET, 8 * 27 * 5 * 10 * 14 * 8
+    with torch.no_grad():
+        a = conv(xs)
+        F64_COLUMN_BUDGET = 1e30
+        b = conv(xs)
+    F64_COLUMN_BUDGET = keep_budget
+    assert float((a - b).abs().max()) < 1e-14, float((a - b).abs().max())
+    ref = ref.double()
+    keep, hooks = {}, []
+    if case["model"] == "gcnet":
+        hooks.append(ref.deconv5.register_forward_hook(lambda m, i, o: keep.__setitem__("deconv5", o.detach().clone())))
+        tapname = "deconv5"
+    else:
+        ref_psm.left = torch.empty(1, 3, H, W)          # D2
+        for t in ("classif1", "classif2", "classif3"):
+            hooks.append(getattr(ref, t).register_forward_hook(lambda m, i, o, t=t: keep.__setitem__(t, o.detach().clone())))
+        tapname = "cost3"
+    with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+        disp = ref(x.double())
+    for h in hooks:
+        h.remove()
+    assert disp.dtype == torch.float64, disp.dtype
+    tap = keep["deconv5"] if case["model"] == "gcnet" else keep["classif3"] + (keep["classif2"] + keep["classif1"])
+    assert tap.dtype == torch.float64
+    flat = tap.reshape(-1)
+    stride = max(1, flat.numel() // NS)
+    assert stride == int(gold["tapstride_" + tapname])
+    ts = flat[::stride].numpy().copy()
+    base = torch.from_numpy(gold["disp"]).double()
+    e = (disp - base).abs().flatten()
+    q = lambda f: float(e.kthvalue(max(1, int(f * e.numel())))[0])      # noqa: E731
+    g = gold["tap_" + tapname].astype(np.float64)
+    out = {"state_sha256": gold["state_sha256"], "disp_f64": disp.numpy(), "tap_%s_f64" % tapname: ts,
+           "ref32_vs_f64": np.array([q(0.5), q(0.99), q(0.999), float(e.max())])}
+    path = os.path.join(HERE, "fullsize_%s_f64.npz" % name)
+    np.savez_compressed(path, **out)
+    print("%-24s float64 reference: |ref_f32 - ref_f64| median %.3e p99 %.3e p99.9 %.3e max %.3e; %.3f%% <= 1e-3; logit samples rel "
+          "%.2e  -> %s (%.2f MB, %.0f s)" % (name, q(0.5), q(0.99), q(0.999), float(e.max()), 100 * float((e <= 1e-3).double().mean()),
+                                            float(np.abs(ts - g).max() / max(1.0, float(np.abs(ts).max()))), os.path.basename(path),
+                                            os.path.getsize(path) / 1e6, time.time() - t0), flush=True)
 
 
 def softmax_stats(logits):
@@ -211,8 +306,11 @@ def run_case(name, case):
 
 
 if __name__ == "__main__":
-    args = [a for a in sys.argv[1:] if a != "--alt"]
-    if "--alt" in sys.argv[1:]:
+    args = [a for a in sys.argv[1:] if a not in ("--alt", "--f64")]
+    if "--f64" in sys.argv[1:]:
+        for name in args or list(recipes.F64_CASES):
+            run_f64(name, recipes.FULL_CASES[name])
+    elif "--alt" in sys.argv[1:]:
         for name in args or list(recipes.ALT_CASES):
             run_alt(name, recipes.FULL_CASES[name])
     else:

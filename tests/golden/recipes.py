@@ -54,6 +54,10 @@ ALT_CASES = ("psmnet_cfg3", "psmnet_cfg3_peaky", "gcnet_cfg2_peaky", "gcnet_cfg5
 # torch.backends.mkldnn.flags(enabled=False), i.e. ATen's vol2col + GEMM convolutions instead of oneDNN's direct ones (needs
 # 43 GB for the column buffer of MS-GCNet's conv3dbn_2: run it alone in the build container).
 ALT_VARIANTS = ("t1", "nomkldnn")
+# Round 6: the same cases once more with the unmodified reference moved to FLOAT64 (make_fullsize_golden.py --f64):
+# fullsize_<case>_f64.npz holds the mathematically exact disparity map, so the tests can say how far the reference's own float32
+# forward and the HIP forward each sit from the truth.
+F64_CASES = ALT_CASES
 FULL_MAX_SAMPLES = 65536
 
 

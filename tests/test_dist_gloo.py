@@ -1,7 +1,9 @@
-"""CPU, world_size 2, gloo: the rank-sharding + all-gather contract of ms-nets_amd/dist.py."""
+"""CPU, gloo, world_size 2 and 8: the rank-sharding + all-gather contract of ms-nets_amd/dist.py.  The world-size-8 cases run
+BASELINE.json configs #4 / #5's index arithmetic (n_total 32 -> 4 per rank, 16 -> 2 per rank) with the map shape scaled down."""
 import os
 import socket
 
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -14,7 +16,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, n_total, q):
+def _worker(rank, world, port, n_total, q, hw=(3, 5)):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
     import sys
@@ -24,23 +26,25 @@ def _worker(rank, world, port, n_total, q):
     r, w, _ = msdist.init_from_env(backend="gloo")
     assert (r, w) == (rank, world)
     mine = msdist.shard_indices(n_total, r, w)
-    H, W = 3, 5
-    local = torch.stack([torch.full((H, W), float(i)) for i in mine]) if mine else torch.zeros((0, H, W))
+    H, W = hw
+    # map i carries i in every pixel plus a per-pixel ramp, so a mis-ordered or mis-strided gather cannot pass on corners alone
+    ramp = torch.arange(H * W, dtype=torch.float32).view(H, W) / 1024.0
+    local = torch.stack([torch.full((H, W), float(i)) + ramp for i in mine]) if mine else torch.zeros((0, H, W))
     out = msdist.gather_disparities(local, n_total)
     msdist.barrier()
-    q.put((rank, mine, out[:, 0, 0].tolist(), tuple(out.shape)))
+    whole = bool(torch.equal(out, torch.arange(n_total, dtype=torch.float32).view(-1, 1, 1) + ramp))
+    q.put((rank, mine, out[:, 0, 0].tolist(), tuple(out.shape), whole))
     torch.distributed.destroy_process_group()
 
 
-def _run(n_total):
-    world = 2
+def _run(n_total, world=2, hw=(3, 5)):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    ps = [ctx.Process(target=_worker, args=(r, world, port, n_total, q)) for r in range(world)]
+    ps = [ctx.Process(target=_worker, args=(r, world, port, n_total, q, hw)) for r in range(world)]
     for p in ps:
         p.start()
-    res = [q.get(timeout=120) for _ in ps]
+    res = [q.get(timeout=300) for _ in ps]
     for p in ps:
         p.join(60)
         assert p.exitcode == 0
@@ -50,15 +54,34 @@ def _run(n_total):
 def test_even_batch_round_robin_and_order():
     res = _run(4)
     assert res[0][1] == [0, 2] and res[1][1] == [1, 3]           # sample i -> rank i mod world
-    for _, _, vals, shape in res:
-        assert shape == (4, 3, 5) and vals == [0.0, 1.0, 2.0, 3.0]   # original order on every rank
+    for _, _, vals, shape, whole in res:
+        assert shape == (4, 3, 5) and vals == [0.0, 1.0, 2.0, 3.0] and whole   # original order on every rank
 
 
 def test_uneven_batch_is_padded_for_the_collective():
     res = _run(3)
     assert res[0][1] == [0, 2] and res[1][1] == [1]
-    for _, _, vals, shape in res:
-        assert shape == (3, 3, 5) and vals == [0.0, 1.0, 2.0]
+    for _, _, vals, shape, whole in res:
+        assert shape == (3, 3, 5) and vals == [0.0, 1.0, 2.0] and whole
+
+
+@pytest.mark.parametrize("n_total,per_rank,hw", [(32, 4, (17, 30)),     # config #4: 32 pairs of 544x960 over 8 GPUs, maps /32
+                                                 (16, 2, (12, 39)),     # config #5: 16 pairs of 384x1248 over 8 GPUs, maps /32
+                                                 (13, None, (5, 7))])   # ragged: ranks 0-4 hold 2, ranks 5-7 hold 1 (padded)
+def test_world_size_8_index_arithmetic(n_total, per_rank, hw):
+    """The exact 8-rank sharding / padding / re-ordering the driver's 8-GPU bench would exercise (main_msnet.py:174's
+    DataParallel share), over gloo on CPU.  No scaling curve is implied by this -- it is index arithmetic."""
+    world = 8
+    res = _run(n_total, world=world, hw=hw)
+    assert [r[0] for r in res] == list(range(world))
+    owned = []
+    for rank, mine, vals, shape, whole in res:
+        assert mine == list(range(rank, n_total, world))
+        if per_rank is not None:
+            assert len(mine) == per_rank
+        assert shape == (n_total,) + hw and vals == [float(i) for i in range(n_total)] and whole
+        owned += mine
+    assert sorted(owned) == list(range(n_total))                 # every pair computed exactly once
 
 
 def test_single_process_is_identity():

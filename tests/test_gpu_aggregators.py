@@ -1226,3 +1226,59 @@ def test_psmnet_forward_ndhwc_equals_forward(gpu):
     with pytest.raises(ValueError):
         m.forward_ndhwc(vol.unsqueeze(0))
 
+
+
+def test_check_input_range_any_length_and_alignment(gpu):
+    """msnet_check_input_range takes any count and any float alignment (scalar edges around whole float4 reads); a bad
+    value is found wherever it sits -- in the unaligned head, in the body, in the tail."""
+    from msnets_amd import hipops
+    base = torch.rand(4099, device="cuda")
+    for off in (0, 1, 2, 3):
+        for n in (1, 2, 3, 4, 5, 7, 8, 1021, 4090):
+            for pos in (None, 0, n - 1, n // 2):
+                x = base[off:off + n].clone() if off == 0 else base[off:off + n]      # a view: data_ptr() is 4 * off past alignment
+                keep = None
+                if pos is not None:
+                    keep = float(base[off + pos])
+                    base[off + pos] = float("inf") if (pos + n) % 2 else 7e4
+                    x = base[off:off + n]
+                with hipops.RangeGuard(x.device) as g:
+                    hipops.check_input_range(x)
+                    torch.cuda.synchronize()
+                    word = g.word()
+                if keep is not None:
+                    base[off + pos] = keep
+                assert word == (0 if pos is None else hipops.RangeGuard.INPUT), (off, n, pos, word)
+
+
+def test_conv_on_module_input_carries_the_range_check(gpu):
+    """Round 6: msnet_conv3d_k3_in_f16s == msnet_conv3d_k3_f16s bit for bit, and raises RangeGuard.INPUT for a bad module input
+    wherever it sits -- on the tiled Co = 32 kernel (64 -> 32 at 8x32x64: the check rides in the loaders, no pass over the
+    volume) and on a shape that kernel does not take (64 -> 32 at 4x8x24: the direct kernel behind msnet_check_input_range)."""
+    from msnets_amd import hipops
+    torch.manual_seed(5)
+    for (d, h, w) in ((8, 32, 64), (6, 21, 70), (4, 8, 24)):
+        conv = torch.nn.Conv3d(64, 32, 3, padding=1, bias=False)
+        bn = torch.nn.BatchNorm3d(32).eval()
+        p = hipops.ConvBNPlan(conv.cuda(), bn.cuda(), precision="split-fp16")
+        x = torch.rand(2, d, h, w, 64, device="cuda") * 4 - 2
+        with hipops.RangeGuard(x.device) as g:
+            y_in = hipops.conv3d_k3_in(x, p.wpk, p.scale, p.shift, p.co, relu=True)
+            torch.cuda.synchronize()
+            assert g.word() == 0
+        y = hipops.conv3d_k3(x, p.wpk, p.scale, p.shift, p.co, relu=True, f16s=True)
+        assert torch.equal(y_in, y), (d, h, w)
+        for pos, val in (((0, 0, 0, 0, 0), float("nan")), ((1, d - 1, h - 1, w - 1, 63), float("inf")), ((0, d // 2, h // 2, w // 2, 37), -5e4),
+                         ((1, 0, h - 1, 0, 31), 32752.0)):
+            bad = x.clone()
+            bad[pos] = val
+            with hipops.RangeGuard(x.device) as g:
+                hipops.conv3d_k3_in(bad, p.wpk, p.scale, p.shift, p.co, relu=True)
+                torch.cuda.synchronize()
+                assert g.word() & hipops.RangeGuard.INPUT, (d, h, w, pos, val)
+        ok = x.clone()
+        ok[0, 1, 2, 3, 4] = 32000.0                      # inside the range: no input bit (the activation bit may rise downstream)
+        with hipops.RangeGuard(x.device) as g:
+            hipops.conv3d_k3_in(ok, p.wpk, p.scale, p.shift, p.co, relu=True)
+            torch.cuda.synchronize()
+            assert not (g.word() & hipops.RangeGuard.INPUT)

@@ -75,6 +75,9 @@ def test_bench_cpu_baseline_leg(gpu):
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "maps/s" and c["sample"]
     assert c["volume_s"] > 0 and c["aggregator_s"] > 0 and abs(1.0 / (c["volume_s"] + c["aggregator_s"]) - c["value"]) < 1e-9
+    # a warm-up plus >= 3 timed maps, the median reported, thread counts stated
+    assert c["samples"] == 3 and len(c["map_s"]) == 3 and abs(1.0 / sorted(c["map_s"])[1] - c["value"]) < 1e-2 * c["value"]
+    assert c["torch_num_threads"] == c["cores"] and "omp_num_threads_env" in c and c["host_cpus"] >= c["cores"]
 
 
 def test_bench_under_torchrun_uses_rccl(gpu):

@@ -45,6 +45,9 @@ KAPPA_FLAT = 1.0        # pixels at least this well conditioned must meet the fl
 # every K = 2 products, the fp16 MFMA after every 16).  "beyond": fraction of pixels past the flat 1e-3.
 NOISE_FACTOR = {"HIP split-fp16": {"p99": 1.25, "p99.9": 1.25, "max": 1.5, "beyond": 1.5},
                 "HIP exact fp32": {"p99": 2.0, "p99.9": 2.0, "max": 2.5, "beyond": 4.0}}
+# gate X (round 6): |HIP - exact| against |reference float32 - exact|, exact = the reference in float64
+EXACT_FACTOR = {"HIP split-fp16": {"p99": 1.25, "p99.9": 1.25, "max": 1.5, "beyond": 1.5},
+                "HIP exact fp32": {"p99": 2.0, "p99.9": 2.0, "max": 2.5, "beyond": 4.0}}
 # fraction of the map within a flat 1e-3: the value measured in round 3 (profiles/r03x_parity_errors.txt) minus half a point
 FRAC_FLAT_MIN = {"gcnet_cfg1_ms": 0.995, "gcnet_cfg2": 0.995, "gcnet_cfg5": 0.995, "gcnet_cfg2_ms_unimodal": 0.995, "gcnet_cfg2_peaky": 0.9897,
                  "gcnet_cfg2_ms_peaky": 0.9946, "gcnet_cfg5_peaky": 0.9936, "psmnet_cfg3": 0.9918, "psmnet_cfg3_peaky": 0.9743}
@@ -189,6 +192,29 @@ def test_fullsize_vs_reference(gpu, name):
                     assert st[k] <= max(fac * floor[k], DISP_TOL), (label, k, st[k], floor[k])
             assert st["beyond"] <= NOISE_FACTOR[label]["beyond"] * floor["beyond"] + 1e-3, (label, st["beyond"], floor["beyond"])
         print("%s: logit samples, relative: reference-vs-reference %.2e, HIP split-fp16 vs reference %.2e" % (name, lfloor, logit_rel))
+        # ---- X (round 6): against the EXACT answer.  fullsize_<case>_f64.npz = the unmodified reference moved to float64
+        # (make_fullsize_golden.py --f64).  The reference's own float32 forward is |ref - exact| away from the truth; the HIP
+        # forward must not be further from it than EXACT_FACTOR x that (or inside the flat 1e-3): no float32 implementation can
+        # be asked to be closer to another float32 implementation than both are to the exact result, and gate N's floor --
+        # the reference against itself under other thread counts -- shares most of its roundings between the variants.
+        f64_path = os.path.join(GOLD, "fullsize_%s_f64.npz" % name)
+        assert os.path.exists(f64_path), f64_path
+        g64 = np.load(f64_path)
+        assert str(g64["state_sha256"]) == str(gold["state_sha256"])
+        exact = torch.from_numpy(g64["disp_f64"])
+        ref_x = _stats((ref.double() - exact).abs())
+        print("%s: reference float32 vs EXACT (reference in float64): p99 %.2e p99.9 %.2e max %.2e, %.3f%% beyond 1e-3" % (
+            name, ref_x["p99"], ref_x["p99.9"], ref_x["max"], 100 * ref_x["beyond"]))
+        for label, dmap in (("HIP split-fp16", disp), ("HIP split-fp16, un-fused tail", disp_t), ("HIP exact fp32", d32)):
+            st = _stats((dmap.double() - exact).abs())
+            print("%s: %s vs EXACT: p99 %.2e p99.9 %.2e max %.2e, %.3f%% beyond 1e-3  |  x the reference's own distance: "
+                  "p99 %.2f p99.9 %.2f max %.2f" % (name, label, st["p99"], st["p99.9"], st["max"], 100 * st["beyond"],
+                                                    st["p99"] / ref_x["p99"], st["p99.9"] / ref_x["p99.9"], st["max"] / ref_x["max"]))
+            fac = EXACT_FACTOR.get(label)
+            if fac:
+                for k in ("p99", "p99.9", "max"):
+                    assert st[k] <= max(fac[k] * ref_x[k], DISP_TOL), (label, k, st[k], ref_x[k])
+                assert st["beyond"] <= fac["beyond"] * ref_x["beyond"] + 1e-3, (label, st["beyond"], ref_x["beyond"])
     # ---- the MS-volume case also runs end to end from the two images through the HIP volume build
     if pair is not None:
         from msnets_amd import cbmv_generator as cg
