@@ -355,6 +355,7 @@ def main():
                          "affine terms (synthetic.randomize_bn, the recipe of the golden fixtures)")
     ap.add_argument("--precision", default="split-fp16", choices=["split-fp16", "fp32"])
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not record per-launch HIP events (diagnostic)")
+    ap.add_argument("--keep-gc", action="store_true", help="leave CPython's cyclic garbage collector enabled inside the timed region")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay the aggregator forward from a captured HIP graph (module.use_graph); its launches then carry no "
@@ -511,21 +512,45 @@ def main():
     torch.cuda.synchronize()
     if meter:
         meter.start()
+    # host hygiene inside the timed region: CPython's cyclic collector is held off (gc.freeze + disable, re-enabled right after) --
+    # a generation-2 pass over torch's module graph takes 10-40 ms and lands in whichever step triggers it (--keep-gc: leave it on).
+    import gc
+    gc_log = []
+    if args.verbose:
+        def _gc_cb(phase, info, _t=[0.0]):
+            if phase == "start":
+                _t[0] = time.perf_counter()
+            else:
+                gc_log.append((info.get("generation"), 1e3 * (time.perf_counter() - _t[0])))
+        gc.callbacks.append(_gc_cb)
+    if not args.keep_gc:
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+    host_ms = []
     t0 = time.perf_counter()
     step_ev[0].record()
     for k in range(args.steps):
+        th = time.perf_counter()
         out = step()
         step_ev[k + 1].record()
+        host_ms.append(1e3 * (time.perf_counter() - th))
     torch.cuda.synchronize()
     msdist.barrier()
     dt = time.perf_counter() - t0
+    if not args.keep_gc:
+        gc.enable()
+        gc.unfreeze()
+    if args.verbose:
+        gc.callbacks.remove(_gc_cb)
     power = meter.stop() if meter else None
     if power and power["power_w"] is not None:
         power["energy_j_per_map"] = power["power_w"] * dt / (args.steps * B)
     _lib.prof_enable(False)
     prof = _lib.prof_collect()
     all_timed = dom_prefix is None and not args.no_kernel_timing
-    per_step = sorted(step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps))
+    step_series = [step_ev[k].elapsed_time(step_ev[k + 1]) for k in range(args.steps)]
+    per_step = sorted(step_series)
     guard_tripped = model._forced_precision is not None           # the fp16-range guard moved the module to fp32 (hipops)
 
     dt_local = dt
@@ -646,7 +671,9 @@ def main():
                                    "fixtures' recipe)") + " -- no trained checkpoint exists offline"),
                        "range_guard_tripped": bool(guard_tripped)},
             "power": power,
-            "step_ms": {"median": pct(50), "p10": pct(10), "p90": pct(90), "source": "HIP events between steps, rank 0"},
+            "step_ms": {"median": pct(50), "p10": pct(10), "p90": pct(90), "source": "HIP events between steps, rank 0",
+                        "in_order": [round(t, 3) for t in step_series], "host_issue_ms_in_order": [round(t, 3) for t in host_ms],
+                        "python_gc": "enabled" if args.keep_gc else "frozen + disabled over the timed region"},
             "roofline": {"bound": "mfma", "kernel": dom_name, "family": dom_family,
                          "dominant_by": "largest total kernel time per step (all families under HIP events, %s)" % (
                              "timed region" if all_timed else "post-pass of %d untimed steps" % post_steps),
@@ -727,6 +754,9 @@ def main():
                     k, v["calls"], v["ms"] / args.steps, 100 * v["ms"] / tot, tf, gb), file=sys.stderr)
             print("  kernels %.3f ms/step of %.3f ms/step wall" % (tot / args.steps, 1e3 * dt / args.steps), file=sys.stderr)
             print("  per-step ms (sorted): " + " ".join("%.2f" % t for t in per_step), file=sys.stderr)
+            print("  per-step ms (in order): " + " ".join("%.2f" % t for t in step_series), file=sys.stderr)
+            print("  host issue ms (in order): " + " ".join("%.2f" % t for t in host_ms), file=sys.stderr)
+            print("  python gc passes inside the timed region (generation, ms): %s" % gc_log, file=sys.stderr)
         if world == 1 and not args.no_extras:
             pk = measure_peaks(dev)
             line["peaks_measured"] = dict(pk, note="this device, this run: float4 copy of 1 GiB (read + write bytes); register-only "

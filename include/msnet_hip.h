@@ -246,8 +246,10 @@ int msnet_deconv5_softargmin(const float* x, const float* w, float bias_host, fl
 /* The same tail with a caller-owned workspace (msnet_deconv5_softargmin_workspace_bytes(N, D, H, W) bytes; 0 = not needed): a
  * tile's D slices are then cut into depth segments, one workgroup each, whose online-softmax states (max, sum e, sum d*e per
  * output pixel) meet in a small merge pass -- at the benchmark shapes the single chain per tile leaves the CUs 2.4 workgroups
- * each and is latency-bound.  The segmentation depends on (D, H, W) only, never on N, so a batch returns its samples' single-
- * forward bits.  Same logits, same order of pushes inside a segment; against the plain entry the result differs by the
+ * each and is latency-bound.  The segmentation depends on (D, H, W) only -- never on N (a batch returns its samples' single-forward
+ * bits) and never on the CU count the runtime reports (fixed 256-CU sizing: the same bits on every gfx950 box, partition mode and
+ * CU-masked stream).  Test hook, not an interface: the environment variable MSNET_TAIL_SEGS=<n> forces n segments
+ * (tests/test_gpu_aggregators.py::test_fused_tail_depth_segments); leave it unset anywhere results must reproduce.  Same logits, same order of pushes inside a segment; against the plain entry the result differs by the
  * rounding of where the segments' fp32 sums are joined (parity tests hold both against the oracle at the same tolerance). */
 size_t msnet_deconv5_softargmin_workspace_bytes(int N, int D, int H, int W);
 int msnet_deconv5_softargmin_ws(const float* x, const float* w, float bias_host, float wscale, float* disp, int N, int D,

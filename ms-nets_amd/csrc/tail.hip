@@ -707,7 +707,10 @@ static int tail_segments(int D, int H, int W) {
         if (v >= 1) return v < D ? v : D;
     }
     const long tiles = (long)cdiv(H, 7) * cdiv(W, 31);
-    const long slots = 4L * num_cus_tail();
+    // The segment count decides the order in which a pixel's partial softmax sums meet, i.e. the disparity's last bits: it is a
+    // function of (D, H, W) ALONE -- 256 CUs, the gfx950 part this library is built for -- never of the CU count the runtime
+    // reports (a partitioned device, a CU-masked stream) so that results reproduce across boxes and partition modes.
+    const long slots = 4L * 256;
     // round(2.4 x slots / tiles): measured in the network at 272x480 (624 tiles, 1024 slots), tail + merge pass, one box
     // (profiles/r05_tail_segments.txt): 1 run 0.393 ms, 2: 0.367, 3: 0.363, 4: 0.355, 6: 0.374
     long nseg = (24 * slots + 5 * tiles) / (10 * tiles);
