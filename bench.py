@@ -121,10 +121,16 @@ class PowerMeter:
             return None
         return e.value * res.value * 1e-6
 
-    def start(self):
-        from msnets_amd import _lib
+    def start_energy(self):
         self.e0, self.t0 = self._energy_j(), time.perf_counter()
+
+    def start_clock(self):
+        from msnets_amd import _lib
         _lib.check(_lib.load().msnet_clock_probe(_lib.ptr(self.clk), _lib.stream_ptr()), "msnet_clock_probe")
+
+    def start(self):
+        self.start_energy()
+        self.start_clock()
 
     def stop(self):
         """Call behind the region's closing synchronize."""
@@ -481,6 +487,18 @@ def main():
     # Under RCCL the first barrier creates the communicator and the first step after each of the first barriers is tens
     # of milliseconds slow (lazy RCCL/runtime initialisation), so the setup alternates barriers and steps until that is
     # over -- otherwise it would land in the timed region, whose opening barrier the contract fixes.
+    # Everything the timed region needs is created HERE, in front of the first step the device ever runs (round 6): loading
+    # rocm_smi_lib and rsmi_init take 0.1-0.5 s, and while that sat between the warm-up and the timed region the GPU idled, dropped
+    # its clocks, and the first three timed steps ran 8.4 / 7.5 / 7.1 ms against 6.97 in the steady state
+    # (profiles/r06_step_series.txt) -- 1.5-2.5 % of a 20-step headline that measured the idle gap, not the path.  From the first
+    # setup step to the closing synchronize the device now only ever waits for the host's short synchronisation points.
+    import gc
+    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    meter = PowerMeter(local, dev) if rank == 0 else None
+    if meter:
+        meter._energy_j()                               # (first call opens the sysfs file behind the counter)
+    if not args.keep_gc:
+        gc.collect()                                    # (tens of ms: here, not between the warm-up and the timed region)
     for _ in range(3):
         msdist.barrier()
         out = step()
@@ -493,10 +511,7 @@ def main():
         assert torch.equal(gathered[i], mine[j]), "all-gather order: sample %d is not rank %d's map %d" % (i, rank, j)
     del mine, gathered
 
-    for _ in range(args.warmup):
-        out = step()
-    torch.cuda.synchronize()
-    assert out.shape == (n_total, H, W) and bool(torch.isfinite(out).all())
+    assert out.shape == (n_total, H, W) and bool(torch.isfinite(out).all())      # (the setup steps' result: checked before the warm-up, not behind it)
 
     # HIP events inside the timed region: around the launches of the stride-1 conv families (one of them is the step's largest
     # family by total time in every workload) and the volume build only -- the two event records per launch cost 0.18 ms per
@@ -505,16 +520,22 @@ def main():
     f16path = args.precision != "fp32"
     timed_families = ("conv3d_s1_wd_f16s", "conv3d_s1_f16s_co") if f16path else ("conv3d_s1",)
     dom_prefix = None if args.verbose else ",".join(timed_families + VOLUME_FAMILIES)
+    # the gc hygiene of the timed region starts in front of the warm-up (nothing but the W steps between here and the barrier)
+    if not args.keep_gc:
+        gc.freeze()
+        gc.disable()
+    # exactly W warm-up steps, and nothing between the last of them and the opening barrier + synchronize but two host calls
+    for _ in range(args.warmup):
+        out = step()
     _lib.prof_enable(not args.no_kernel_timing, dom_prefix)
-    step_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    meter = PowerMeter(local, dev) if rank == 0 else None
+    if meter:
+        meter.start_energy()                            # (a sysfs read: in front of the barrier, not between it and the first step)
     msdist.barrier()
     torch.cuda.synchronize()
     if meter:
-        meter.start()
+        meter.start_clock()
     # host hygiene inside the timed region: CPython's cyclic collector is held off (gc.freeze + disable, re-enabled right after) --
     # a generation-2 pass over torch's module graph takes 10-40 ms and lands in whichever step triggers it (--keep-gc: leave it on).
-    import gc
     gc_log = []
     if args.verbose:
         def _gc_cb(phase, info, _t=[0.0]):
@@ -523,10 +544,6 @@ def main():
             else:
                 gc_log.append((info.get("generation"), 1e3 * (time.perf_counter() - _t[0])))
         gc.callbacks.append(_gc_cb)
-    if not args.keep_gc:
-        gc.collect()
-        gc.freeze()
-        gc.disable()
     host_ms = []
     t0 = time.perf_counter()
     step_ev[0].record()

@@ -34,23 +34,14 @@ __global__ void pack_weight_c8_f16s_kernel(const float* __restrict__ w, _Float16
 // this path.  The fp16-range check of the module input, which that pass carried, is made here on the staged values (bit 1 of
 // the overflow word).  Slots: thread t holds voxels t, t+256, ... of the tile, both channel quads (NL = 2 * ceil(NPOS/256)).
 // INCHK: the input IS the module input (NCS, or a channels-last volume handed to forward_ndhwc): check its fp16 range here.
-// EXP_C8_WG3 (round 6 experiment): THREE workgroups per CU for the Co = 32 layer.  Two leave 54,784 B x 3 = 164,352 B, 512 bytes
-// over the 160 KB of LDS; the last K-step (tap 26 | the zero tap 27) is therefore held in eight registers per lane instead of
-// LDS (52,736 B per workgroup, 158,208 B for three) and the register budget drops to 512 / 3 = 170 per lane.
-#ifdef EXP_C8_WG3
-#define C8_WGS(NB) ((NB) == 1 ? 3 : 1)
-#define C8_LDS_STEPS(NB) ((NB) == 1 ? 13 : 14)
-#else
-#define C8_WGS(NB) ((NB) == 1 ? 2 : 1)
-#define C8_LDS_STEPS(NB) 14
-#endif
+// (Round 6: THREE workgroups per CU -- the last K-step's weights in registers so that 3 x 52,736 B fit the LDS, 170 registers per
+// lane -- was built and measured: 27-60 spilled registers, layer +20 %, step -3.6 %; profiles/r06_c8_wg3.txt.)
 template <int NB, bool NCS, bool INCHK = NCS>
-__global__ __launch_bounds__(256, C8_WGS(NB)) void conv3d_c8_f16s_kernel(ConvArgs a) {    // (Co = 64: 128 accumulator registers, one workgroup per CU)
+__global__ __launch_bounds__(256, NB == 1 ? 2 : 1) void conv3d_c8_f16s_kernel(ConvArgs a) {    // (Co = 64: 128 accumulator registers, one workgroup per CU)
     constexpr int TD = 2, TH = 4, TW = 32, ID = TD + 2, IH = TH + 2, IW = TW + 2, NPOS = ID * IH * IW;
     constexpr int NSLOT = NCS ? ((NPOS + 255) / 256) * 512 : NPOS * 2;
     constexpr int NL = (NSLOT + 255) / 256;                             // float4 (channel quads) per thread per tile
-    constexpr int LSTEPS = C8_LDS_STEPS(NB);                            // K-steps whose weights live in LDS (the rest: registers)
-    constexpr int WB = LSTEPS * NB * 2 * 1024;
+    constexpr int WB = 14 * NB * 2 * 1024;
     __shared__ __attribute__((aligned(16))) unsigned char lds_a[NPOS * 32];
     __shared__ __attribute__((aligned(16))) unsigned char lds_b[WB];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -63,14 +54,6 @@ __global__ __launch_bounds__(256, C8_WGS(NB)) void conv3d_c8_f16s_kernel(ConvArg
         const u32x4* src = reinterpret_cast<const u32x4*>(a.wpk);
         u32x4* dst = reinterpret_cast<u32x4*>(lds_b);
         for (int k = tid; k < WB / 16; k += 256) dst[k] = src[k];
-    }
-    [[maybe_unused]] half8 breg_h[NB], breg_l[NB];       // weights of K-step 13 when it is not in LDS
-    if constexpr (LSTEPS < 14) {
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            breg_h[j] = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.wpk)[((13 * NB + j) * 2) * 64 + lane]);
-            breg_l[j] = __builtin_bit_cast(half8, reinterpret_cast<const u32x4*>(a.wpk)[((13 * NB + j) * 2 + 1) * 64 + lane]);
-        }
     }
     // loader role: slot = u*256 + tid -> (pos = slot >> 1, quad = slot & 1).  Per-slot constants (position in the tile, byte
     // offset from the tile origin) are computed once; an interior tile costs one add + one buffer load per slot.
@@ -99,19 +82,6 @@ __global__ __launch_bounds__(256, C8_WGS(NB)) void conv3d_c8_f16s_kernel(ConvArg
     ctr.init(lb, G, 1, a.ntw, a.nth, a.ntd, 1);
     nxt = ctr;
     auto issue_a = [&](const TileCtr& c) {
-#ifdef EXP_C8_WG3
-        {   // at 170 registers the 2 x NL slot constants are recomputed per tile instead of living in registers for the whole kernel
-            int tid_o = tid;
-            asm volatile("" : "+v"(tid_o));
-#pragma unroll
-            for (int u = 0; u < NL; ++u) {
-                const int pos = NCS ? (u >> 1) * 256 + tid_o : (u * 256 + tid_o) >> 1, q = NCS ? (u & 1) : ((u * 256 + tid_o) & 1);
-                const int iw = pos % IW, ih = (pos / IW) % IH, id = pos / (IW * IH);
-                rel_[u] = NCS ? (unsigned)(((id * a.H + ih) * a.W + iw) * 4) : (unsigned)((((id * a.H + ih) * a.W + iw) * 8 + q * 4) * 4);
-                dhw_[u] = pos < NPOS ? ((id << 16) | (ih << 8) | iw) : -1;
-            }
-        }
-#endif
         const int d0 = c.td * TD, h0 = c.th * TH, w0 = c.tw * TW;
         const unsigned base = (unsigned)(((((long)(d0 - 1) * a.H + (h0 - 1)) * a.W + (w0 - 1)) * (NCS ? 1 : 8)) * 4);   // may wrap; in-range slots bring it back
         const bool interior = d0 >= 1 && d0 - 1 + ID <= a.D && h0 >= 1 && h0 - 1 + IH <= a.H && w0 >= 1 && w0 - 1 + IW <= a.W;
@@ -178,11 +148,6 @@ __global__ __launch_bounds__(256, C8_WGS(NB)) void conv3d_c8_f16s_kernel(ConvArg
             for (int j = 0; j < NB; ++j)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) { acc0[i][j][e] = 0.f; acc1[i][j][e] = 0.f; }
-#ifdef EXP_C8_WG3
-        // (opaque per tile: hipcc otherwise hoists the 2 x 14 x 2 fragment addresses out of the tile loop -- 56 registers live for the
-        // whole kernel, which the 170-register budget of three workgroups per CU cannot hold without spilling)
-        asm volatile("" : "+v"(vox0[0]), "+v"(vox0[1]));
-#endif
         static_for<14>([&](auto sc_) {
             constexpr int sstep = decltype(sc_)::value;
             constexpr int t0 = 2 * sstep, t1 = 2 * sstep + 1 < 27 ? 2 * sstep + 1 : 26;
@@ -198,13 +163,8 @@ __global__ __launch_bounds__(256, C8_WGS(NB)) void conv3d_c8_f16s_kernel(ConvArg
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                if constexpr (sstep < LSTEPS) {
-                    bh_[j] = *reinterpret_cast<const half8*>(lds_b + ((sstep * NB + j) * 2) * 1024 + lane * 16);
-                    bl[j] = *reinterpret_cast<const half8*>(lds_b + ((sstep * NB + j) * 2 + 1) * 1024 + lane * 16);
-                } else {
-                    bh_[j] = breg_h[j];
-                    bl[j] = breg_l[j];
-                }
+                bh_[j] = *reinterpret_cast<const half8*>(lds_b + ((sstep * NB + j) * 2) * 1024 + lane * 16);
+                bl[j] = *reinterpret_cast<const half8*>(lds_b + ((sstep * NB + j) * 2 + 1) * 1024 + lane * 16);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -214,9 +174,6 @@ __global__ __launch_bounds__(256, C8_WGS(NB)) void conv3d_c8_f16s_kernel(ConvArg
                     acc1[i][j] = mfma16(al[i], bh_[j], acc1[i][j]);
                     acc1[i][j] = mfma16(ah[i], bl[j], acc1[i][j]);
                 }
-#ifdef EXP_C8_WG3
-            if constexpr (sstep % 2 == 1) __builtin_amdgcn_sched_barrier(0);     // at 170 registers: no more than two K-steps of fragments in flight
-#endif
         });
         // epilogue: lane = output channel, register e = voxel (e&3) + 8*(e>>2) + 4*hh of the 32-voxel row
         const auto rs_y = make_rsrc(a.y + (size_t)n * (osample / 4), osample);
@@ -268,7 +225,7 @@ static int launch_c8_f16s(const char* name, ConvArgs a, hipStream_t s) {
     if (ntiles == 0 || ntiles > 0x7fffffffu) return fail("%s: bad tile count %zu", name, ntiles);
     if ((size_t)a.OD * a.OH * a.OW * a.Co * 4 > 0xfffffff0u || (size_t)a.D * a.H * a.W * 32 > 0xfffffff0u)
         return fail("%s: a sample exceeds the 4 GB buffer-descriptor range", name);
-    const size_t cap = (size_t)C8_WGS(NB) * (size_t)num_cus();
+    const size_t cap = 2 * (size_t)num_cus();
     const size_t nblk = ntiles < cap ? ntiles : cap;
     const double vox = (double)a.N * a.OD * a.OH * a.OW;
     LaunchScope ls(name, s, 2.0 * 27.0 * a.Ci * a.Co * vox,
