@@ -95,19 +95,6 @@ LaunchScope::~LaunchScope() {
 
 using namespace msnet;
 
-#ifdef EXP_WD_PLANAR16
-namespace msnet {
-static float* g_exp_y2 = nullptr;
-static int g_exp_planar_in = 0;
-float* exp_planar_y2() { return g_exp_y2; }
-int exp_planar_in() { return g_exp_planar_in; }
-}  // namespace msnet
-extern "C" int msnet_exp_set_planar(float* y2, int planar_in) {
-    msnet::g_exp_y2 = y2;
-    msnet::g_exp_planar_in = planar_in;
-    return 0;
-}
-#endif
 
 extern "C" int msnet_version(void) { return 1; }
 extern "C" const char* msnet_last_error(void) { return g_err; }

@@ -91,9 +91,6 @@ extern "C" int msnet_conv3d_k3_f16s(const float* x, const void* wpk_f16s, const 
             return direct_launch(false, stride == 2 ? "conv3d_s2_f16s" : (Co == 32 ? "conv3d_s1_f16s_co32" : "conv3d_s1_f16s_co64"),
                                  a, stride, stride == 2 ? 1 : 2, Co == 32 ? 1 : 2, s);
     }
-#ifdef EXP_WD_PLANAR16
-    a.planar_in = (stride == 2 && Ci == 32) ? exp_planar_in() : 0;
-#endif
     if (stride == 2) return ws_launch_s2("conv3d_s2_f16s", a, s);
     if (Ci == 8) return c8_launch(Co == 64 ? 2 : 1, false, false, "conv3d_s1_c8_f16s", a, s);
     if (Ci == 16) return ws_launch_c16(Co == 64, "conv3d_s1_c16_f16s", a, s);

@@ -223,15 +223,8 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
     float psc = 1.f, psh = 0.f, pamax = 0.f;
     bool pend_live = false;
     __amdgpu_buffer_rsrc_t pend_rs = make_rsrc(a.y, 0);
-#ifdef EXP_WD_PLANAR16
-    __amdgpu_buffer_rsrc_t pend_rs2 = make_rsrc(a.y2, 0);
-    unsigned pbase2[2] = {0xffffffffu, 0xffffffffu};
-#endif
     auto park = [&](int n, int od0, int oh0, int ow0) {
         pend_rs = make_rsrc(a.y + (size_t)n * (osample / 4), osample);
-#ifdef EXP_WD_PLANAR16
-        pend_rs2 = make_rsrc(a.y2 ? a.y2 + (size_t)n * (osample / 4) : nullptr, a.y2 ? osample : 0);
-#endif
         const int oh = oh0 + row, owb = ow0 + 4 * hh;
         psc = a.scale ? a.scale[r] : 1.f;
         psh = a.shift ? a.shift[r] : 0.f;
@@ -241,9 +234,6 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
             const bool rowok = od < a.OD && oh < a.OH;
             plw[bb] = rowok ? a.OW - owb : 0;
             pbase[bb] = (unsigned)((((size_t)od * a.OH + oh) * a.OW + owb) * a.Co + r) * 4u;
-#ifdef EXP_WD_PLANAR16
-            pbase2[bb] = (unsigned)((((size_t)(r >> 4) * a.OD * a.OH * a.OW + ((size_t)od * a.OH + oh) * a.OW + owb) * 16 + (r & 15)) * 4u);
-#endif
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const float m0 = acc0[0][e] + acc1[0][e] * kLoInv, m1 = acc0[1][e] + acc1[1][e] * kLoInv;
@@ -263,10 +253,6 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
             if (a.relu) val = fmaxf(val, 0.f);
             pamax = fmaxf(pamax, ok ? fabsf(val) : 0.f);
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), pend_rs, o, 0, 0);
-#ifdef EXP_WD_PLANAR16
-            const unsigned o2 = ok ? pbase2[bb] + (unsigned)(c * 64) : 0xffffffffu;       // (null y2: zero-sized descriptor, dropped)
-            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), pend_rs2, o2, 0, 0);
-#endif
         }
     };
     auto epilogue = [&](int n, int od0, int oh0, int ow0) {
@@ -290,19 +276,6 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
             }
             if (a.res) residual_prefetch<32>(rv, rs_res, off, 0, stride_w * 4, [&](int, int lw) { return rowok && lw < wlim; });
             epilogue_store<32>(v, rv, sc, sh, rs_y, off, 0, stride_w * 4, a.relu, [&](int, int lw) { return rowok && lw < wlim; }, a.oflag);
-#ifdef EXP_WD_PLANAR16
-            if (a.y2 && !a.res) {                       // (a workgroup's LAST tile is stored here, not drained)
-                const auto rs2 = make_rsrc(a.y2 + (size_t)n * (osample / 4), osample);
-                const unsigned off2 = (unsigned)((((size_t)(r >> 4) * a.OD * a.OH * a.OW + ((size_t)od * a.OH + oh) * a.OW + owb) * 16 + (r & 15)) * 4u);
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int c = (e & 3) + 8 * (e >> 2);
-                    float val = v[e] * sc + sh;
-                    if (a.relu) val = fmaxf(val, 0.f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), rs2, (rowok && c < wlim) ? off2 + (unsigned)(c * 64) : 0xffffffffu, 0, 0);
-                }
-            }
-#endif
         }
     };
     // fragment addresses: A = record (k, row + kh, r + kw) = per-lane base [kw][ks] + the immediate ((kh * 4 + k) * IW) * RB;
@@ -374,11 +347,7 @@ __global__ __launch_bounds__(512, 2) void conv3d_wd_f16s_kernel(ConvArgs a) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if constexpr (NRD_ == 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-#ifdef EXP_WD_PLANAR16
-                if constexpr (s % 2 == 0 && s < 64) __builtin_amdgcn_sched_group_barrier(0x040, 2, 0);     // the two drained stores
-#else
                 if constexpr (s % 2 == 0 && s < 64) __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);     // the drained store
-#endif
             }
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (s % 12 == 11 && s < 71) {     // end of a six-tap group
@@ -454,9 +423,6 @@ extern "C" int msnet_conv3d_k3_wd_f16s(const float* x, const void* wpk_wd, const
     a.x = x; a.wpk = reinterpret_cast<const f32x4*>(wpk_wd); a.scale = scale; a.shift = shift; a.res = residual; a.y = y;
     a.N = N; a.D = D; a.H = H; a.W = W; a.Ci = 32; a.Co = 32; a.relu = relu; a.oflag = overflow_flag();
     a.OD = D; a.OH = H; a.OW = W;
-#ifdef EXP_WD_PLANAR16
-    a.y2 = residual ? nullptr : exp_planar_y2();
-#endif
     const int rc = launch_wd_f16s("conv3d_s1_wd_f16s", a, (hipStream_t)stream);
     if (rc < 0) return fail("msnet_conv3d_k3_wd_f16s: a sample exceeds the kernel's 32-bit offset range");
     return rc;

@@ -29,15 +29,7 @@ struct ConvArgs {
     int nbtot;             // Co / 32
     int nseg, seglen;      // sliding-window kernels: depth segments per tile column, tiles (depth steps) per segment
     unsigned* oflag;       // device word that receives 1 when an output leaves the fp16 range (msnet_set_overflow_flag), or null
-#ifdef EXP_WD_PLANAR16     // round 6 experiment (profiles/r06_planar16_pair.txt): variant library only
-    float* y2;             // Winograd-depth kernel: second copy of the output as [2][D][H][W][16] planes, or null
-    int planar_in;         // stride-2 kernel: the input is such a planar tensor
-#endif
 };
-#ifdef EXP_WD_PLANAR16
-float* exp_planar_y2();    // msnet_exp_set_planar(y2, planar_in): api.cpp
-int exp_planar_in();
-#endif
 
 // Range guard of the split-fp16 kernels (conv3d_f16s.hip: every operand's `hi` half is an fp16).  The limit is HALF the largest
 // finite fp16: the Winograd-depth loaders split sums and differences of two activations (q1 = p1 + p2, ...), and those must

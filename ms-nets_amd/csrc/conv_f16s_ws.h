@@ -125,9 +125,6 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
             const int ih = pos / IW, iw = pos % IW;
             const bool ok = slot < PSLOT && c4 * 4 < a.Ci;      // channels beyond Ci are zero padding
             goff_[u] = (unsigned)(((ih * a.W + iw) * a.Ci + c4 * 4) * 4);
-#ifdef EXP_WD_PLANAR16
-            if (STRIDE == 2 && a.planar_in) goff_[u] = (unsigned)(((ih * a.W + iw) * 16 + c4 * 4) * 4);
-#endif
             mask0 |= (ok ? 1u : 0u) << u;
         }
         // LDS offset of this thread's slot u in plane pl: voxel = pl*IH*IW + u*(LT/VR) + lt/VR, channel quad c4 = lt % VR.
@@ -179,14 +176,8 @@ __global__ __launch_bounds__(256 + 64 * LW, (256 + 64 * LW) / 256) void conv3d_k
                 const_cast<float*>(a.x) + (size_t)c.n * (sample_bytes / 4), 0, (int)sample_bytes, 0x00020000);
             // byte offset of voxel (gd, oh0-1, ow0-1), channel chunk*CC, inside the sample (may wrap below zero; the
             // in-range lanes add a positive goff_ that brings it back -- unsigned arithmetic)
-#ifdef EXP_WD_PLANAR16
-            const unsigned base = (STRIDE == 2 && a.planar_in)
-                ? (unsigned)(((long)c.chunk * a.D * a.H * a.W + ((long)gd * a.H + ih0) * a.W + iw0) * 16) * 4u
-                : (unsigned)((((long)gd * a.H + ih0) * a.W + iw0) * a.Ci + c.chunk * CC) * 4u;
-#else
             const unsigned base =
                 (unsigned)((((long)gd * a.H + ih0) * a.W + iw0) * a.Ci + c.chunk * CC) * 4u;
-#endif
             static_assert(PL * LT >= PSLOT, "slots cover the plane");
             const bool plane_ok = live && (unsigned)gd < (unsigned)a.D;
             const bool interior = ih0 >= 0 && ih0 + IH <= a.H && iw0 >= 0 && iw0 + IW <= a.W;

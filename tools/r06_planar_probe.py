@@ -1,6 +1,6 @@
 """Round 6, VERDICT r05 #4: the (conv3dbn_2 -> block_3d_1.convbn_3d_1) pair with the stride-2 consumer reading 16-channel planes.
 
-Variant library only (-DEXP_WD_PLANAR16, MSNET_HIP_LIB=ms-nets_amd/libx_planar16.so): the Winograd-depth kernel writes its output a
+Variant library only (-DEXP_WD_PLANAR16: the kernel-side code lives in commit 9b783ab and was removed from the tree afterwards; MSNET_HIP_LIB=ms-nets_amd/libx_planar16.so): the Winograd-depth kernel writes its output a
 second time as [2][D][H][W][16] planes (one more drained store per element) and the stride-2 kernel's loaders read such a tensor
 (64-byte records: every 16-channel chunk pass is a dense read).  Timed on one box, interleaved, at 96x272x480:
     A  Winograd-depth 32->32 (NDHWC output only)  +  stride-2 32->64 reading NDHWC           (what ships)
