@@ -48,8 +48,8 @@ FP32_MATRIX_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md "Peak FP32 (matrix)", 
 FP16_MATRIX_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md "HBM3E peak BW" (spec); 6290 measured there with a float4 copy
 SPLIT_MFMAS_PER_PRODUCT = 3         # split-fp16: ah*wh, al*wh, ah*wl  
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
-FACTS_FILE = os.path.join(ROOT, "profiles", "r05_profile_facts.json")     # tools/tools_profile_facts.py (rocprofv3 summaries)
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc_traffic.json")
+FACTS_FILE = os.path.join(ROOT, "profiles", "r06_profile_facts.json")     # tools/tools_profile_facts.py (rocprofv3 summaries)
 WORKLOADS = {
     # name: (padded H, W, maxdisp, description)
     "cfg2": (544, 960, 192, "MS-GCNet forward (MS volume build + 19-conv aggregator + soft-argmin), Scene-Flow "
