@@ -57,7 +57,7 @@ ALT_VARIANTS = ("t1", "nomkldnn")
 # Round 6: the same cases once more with the unmodified reference moved to FLOAT64 (make_fullsize_golden.py --f64):
 # fullsize_<case>_f64.npz holds the mathematically exact disparity map, so the tests can say how far the reference's own float32
 # forward and the HIP forward each sit from the truth.
-F64_CASES = ALT_CASES
+F64_CASES = tuple(FULL_CASES)          # every full-size case (the six ALT_CASES first had them; the random-init ones followed)
 FULL_MAX_SAMPLES = 65536
 
 
