@@ -85,6 +85,40 @@ def test_ncc_identical_windows_give_minus_one_and_flat_gives_one():
     assert np.all(n[0, 1:8, 1:10] == 1.0)                       # non-finite normaliser branch (matchers.cpp:203-204)
 
 
+def test_ncc_small_known_answer():
+    """Independent evaluation of nccNister at every valid (i, j, d) from DIRECT window sums (no integral images): every sum is an
+    exact integer in double, so -(n*Sum(LR) - Sum(L)Sum(R)) * Cl * Cr with C = 1/sqrt(n*Sum(x^2) - Sum(x)^2), evaluated left to
+    right in double and cast to float32 (matchers.cpp:146-147,196-204), must reproduce the oracle's integral-image route bit for bit;
+    a non-finite C (constant window) gives 1."""
+    rng = np.random.default_rng(11)
+    l = rng.integers(0, 256, (11, 14), dtype=np.uint8)
+    r = rng.integers(0, 256, (11, 14), dtype=np.uint8)
+    l[2:6, 3:8] = 77                                   # a constant patch: non-finite C for the windows inside it
+    r[5:9, 1:5] = 200
+    nd, ws, wc = 4, 3, 1
+    got = O.nccNister(l, r, nd, ws)
+    H, W = l.shape
+    exp = np.full((nd, H, W), SENT, np.float32)
+    L, R = l.astype(np.int64), r.astype(np.int64)
+    with np.errstate(divide="ignore"):
+        for i in range(H - ws):
+            for j in range(W - ws):
+                wl = L[i:i + ws, j:j + ws]
+                al, bl = int(wl.sum()), int((wl * wl).sum())
+                cl = np.float64(1.0) / np.sqrt(np.float64(ws * ws * bl) - np.float64(al) * np.float64(al))
+                for d in range(min(nd, j + 1)):
+                    wr = R[i:i + ws, j - d:j - d + ws]
+                    ar, br = int(wr.sum()), int((wr * wr).sum())
+                    cr = np.float64(1.0) / np.sqrt(np.float64(ws * ws * br) - np.float64(ar) * np.float64(ar))
+                    if np.isfinite(cl) and np.isfinite(cr):
+                        num = np.float64(ws * ws * int((wl * wr).sum()) - al * ar)
+                        exp[d, i + wc, j + wc] = np.float32(-num * cl * cr)
+                    else:
+                        exp[d, i + wc, j + wc] = np.float32(1.0)
+    assert (exp == np.float32(1.0)).any() and (exp != SENT).sum() > 100
+    assert np.array_equal(got.view(np.uint32), exp.view(np.uint32))
+
+
 def test_sadsob_matches_sequential_float32_integral():
     rng = np.random.default_rng(5)
     sl = rng.integers(-1020, 1021, (10, 13)).astype(np.float32)
@@ -113,6 +147,30 @@ def test_likelihood_properties():
     live = np.delete(np.arange(50), 3)
     assert np.abs(out[live].sum(1) - 1).max() < 1e-5
     assert np.all(out.argmax(1)[live] == vol.argmin(1)[live])    # the cheapest disparity is the most likely
+
+
+def test_likelihood_small_known_answer():
+    """Independent evaluation of extract_likelihood in float32 NumPy, operation by operation (featextract.cpp:415-462): m = min,
+    den = sequential float32 sum of exp(-((c - m)^2) / sigma), out = exp(...) / den.  NumPy's float32 exp and glibc's expf are both
+    faithfully rounded but not the same function: 2 ulp of the result is allowed, nothing more."""
+    f = np.float32
+    rng = np.random.default_rng(12)
+    for sigma, scale in ((128.0, 120.0), (0.02, 2.0), (20000.0, 8192.0)):
+        vol = (rng.random((40, 16), dtype=np.float32) * f(scale)).astype(np.float32)
+        vol[rng.random(vol.shape) < 0.15] = SENT
+        got = O.extract_likelihood(vol, sigma)
+        for i in range(vol.shape[0]):
+            m = vol[i].min()
+            if m == SENT:
+                assert not got[i].any()
+                continue
+            e = np.array([np.exp(f(-(f(f(c - m) * f(c - m)) / f(sigma)))) for c in vol[i]], dtype=np.float32)
+            den = f(0)
+            for x in e:
+                den = f(den + x)
+            exp_row = (e / den).astype(np.float32)
+            assert np.abs(got[i] - exp_row).max() <= 2.5e-7, (sigma, i, float(np.abs(got[i] - exp_row).max()))
+            assert np.all(got[i][vol[i] == SENT] == 0)
 
 
 def test_swap_axes_and_volume_layout():
