@@ -91,6 +91,11 @@ def load():
         raise RuntimeError(
             "libmsnet_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
             "there is no CPU fallback for this path." % LIB_PATH)
+    # torch FIRST: the library needs libamdhip64.so.7 and PyTorch-ROCm loads its own bundled copy of it by path.  With torch's copy
+    # already in the process the loader hands that one to this library too (same SONAME) and both share ONE HIP runtime; loaded the
+    # other way round the process ends up with two runtimes, and the second one to touch the device reports "no ROCm-capable
+    # device is detected" on its first launch (round 6: __graft_entry__.build() followed by smoke() in one process did that).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     variant = bool(os.environ.get("MSNET_HIP_LIB"))
     for name, (res, args) in SIGNATURES.items():

@@ -84,3 +84,24 @@ def test_build_reuses_objects_by_content_not_by_mtime(tmp_path):
     assert build._stale(str(obj), str(obj) + ".sha", build._digest([str(src)], ["-O3"]))      # other bytes
     # the shipped library carries its own stamp, and the stamp matches the objects it was linked from when they are present
     assert os.path.exists(build.LIB + ".sha")
+
+
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """libmsnet_hip.so and PyTorch-ROCm must share ONE libamdhip64 (round 6: loaded before torch, the library pulled in the system
+    copy next to torch's bundled one, and the second runtime to touch the GPU failed with "no ROCm-capable device is detected" --
+    __graft_entry__.build() followed by smoke() in one process).  _lib.load() imports torch first; checked here in a fresh
+    process that loads the library BEFORE anything else has imported torch."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, os; sys.path.insert(0, %r)\n"
+        "assert 'torch' not in sys.modules\n"
+        "import msnets_amd\n"
+        "assert 'torch' not in sys.modules, 'the package import itself must stay light'\n"
+        "msnets_amd._lib.load()\n"
+        "import torch\n"
+        "libs = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+        "print(libs)\n"
+        "assert len(libs) == 1, libs\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
