@@ -41,13 +41,30 @@ __device__ __forceinline__ void split8(const f32x4 a, const f32x4 b, half8_t& hi
 struct SoftArg {
     float m, s, t;
     __device__ __forceinline__ void init() { m = -INFINITY; s = 0.f; t = 0.f; }
-    __device__ __forceinline__ void push(float x, float d) {
-        const float mn = fmaxf(m, x);
-        const float a = expf(m - mn), e = expf(x - mn);
-        s = s * a + e;
-        t = t * a + d * e;
-        m = mn;
+    // The state is rescaled by a = exp(m - mn) and the new term enters as e = exp(x - mn), mn = max(m, x): ONE of the two exponents is
+    // always exactly +0 and expf(+0) == 1.0f exactly, so only the other one is evaluated (round 6).  Same bits as the two-expf form
+    // hipcc generated for `s = s * a + e; t = t * a + d * e` -- s = fma(s, a, e), t = fma(t, a, RN(d * e)): the product is rounded on
+    // its own -- which the explicit fmaf / mul_rn below spell out (fma(s, 1, e) == s + e; RN(d * 1) == d).  NaN / -inf inputs give the
+    // same NaNs.  A wave whose lanes disagree on which side holds the maximum runs both sides, which is what it did before.
+    static __device__ __forceinline__ float mul_rn(float x, float y) {
+        float p = x * y;
+        asm volatile("" : "+v"(p));                    // a product rounded on its own: not a contraction candidate
+        return p;
     }
+    __device__ __forceinline__ void push(float x, float d) {
+        if (x <= m) {                                   // the running maximum stays: a = 1
+            const float e = expf(x - m);
+            s = s + e;
+            t = t + mul_rn(d, e);
+        } else {                                        // x is the new maximum (or NaN): e = 1
+            const float a = expf(m - x);
+            s = __builtin_fmaf(s, a, 1.f);
+            t = __builtin_fmaf(t, a, d);
+            m = fmaxf(m, x);
+        }
+    }
+    // (two logits per step, the fused GCNet tail: the same split was measured there and is NOT used -- bit-identical, but the branch
+    // costs the tail's packed fma / add pairs and runs 0.38 -> 0.41 ms; tools/r06_softarg_ab.py, profiles/r06_softarg_ab.txt)
     __device__ __forceinline__ void push2(float x0, float d0, float x1, float d1) {
         const float mn = fmaxf(m, fmaxf(x0, x1));
         const float a = expf(m - mn), e0 = expf(x0 - mn), e1 = expf(x1 - mn);
